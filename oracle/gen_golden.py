@@ -1,0 +1,270 @@
+"""Capture golden vectors from the reference itself.  Runs ONLY in the build container.
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz
+
+Imports the reference modules from /root/reference (read-only) and HuggingFace ``AlbertModel``
+(the third-party arithmetic the reference calls), feeds them seeded inputs and deterministic
+weights from ``plbert_amd.deterministic_state_dict``, and stores inputs + expected outputs as small
+.npz fixtures.  Nothing here travels to the GPU box except the fixtures; the reference's Python
+never leaves this container.  TEST INFRASTRUCTURE ONLY.
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+torch.set_num_threads(8)
+
+import accelerate  # noqa: E402,F401  (must be imported before the wandb stub: it probes for wandb)
+
+sys.modules.setdefault("wandb", types.ModuleType("wandb"))  # train.py:11 imports it; never called here
+sys.path.insert(0, REF)
+import char_indexer as ref_char_indexer  # noqa: E402
+import dataloader as ref_dataloader  # noqa: E402
+import model as ref_model  # noqa: E402
+import train as ref_train  # noqa: E402
+from transformers import AlbertConfig, AlbertModel  # noqa: E402
+
+import plbert_amd  # noqa: E402
+
+DATASET_PARAMS = dict(word_separator=87, word_pred_prob=0.15, phoneme_mask_prob=0.8, replace_prob=0.1)
+
+
+def obj_array(list_of_lists):
+    a = np.empty(len(list_of_lists), dtype=object)
+    for i, x in enumerate(list_of_lists):
+        a[i] = np.asarray(x, dtype=np.int64)
+    return a
+
+
+def toy_docs():
+    """Small documents over the real vocabulary (IPA + punctuation + an out-of-vocabulary char)."""
+    rs = np.random.RandomState(7)
+    sym = plbert_amd.symbols
+    letters = sym[52:185]
+    docs = []
+    for n_words in (8, 5, 40, 1, 17, 120, 3, 64):
+        words = []
+        for _ in range(n_words):
+            if rs.rand() < 0.12:
+                words.append(sym[1 + rs.randint(0, 51)])            # a punctuation "word"
+            else:
+                words.append("".join(letters[i] for i in rs.randint(0, len(letters), size=rs.randint(1, 9))))
+        docs.append(words)
+    docs[1][2] = docs[1][2] + "¤"                               # '¤' is not in the table -> U
+    return docs
+
+
+def gen_masking():
+    docs = toy_docs()
+    out = {"symbols_codepoints": np.array([ord(c) for c in ref_char_indexer.symbols], dtype=np.int64)}
+    data3 = [{"phonemes": d} for d in docs]
+    rs = np.random.RandomState(11)
+    data4 = [{"phonemes": d, "token_ids": rs.randint(100, 60000, size=len(d)).tolist()} for d in docs]
+    for tag, msl in (("msl512", 512), ("msl32", 32)):
+        # --- 3-tuple stream (use_token_ids=False) -------------------------------------------------
+        np.random.seed(1)
+        random.seed(1)
+        ds = ref_dataloader.MaskedPhonemeDataset(data3, max_seq_length=msl, use_token_ids=False, **DATASET_PARAMS)
+        order = [0, 1, 2, 3, 4, 5, 6, 7, 2, 5, 0, 7, 5, 5, 1, 4]
+        items = [ds[i] for i in order]
+        out[f"{tag}_order"] = np.array(order)
+        out[f"{tag}_labels"] = obj_array([it[0].numpy() for it in items])
+        out[f"{tag}_masked"] = obj_array([it[1].numpy() for it in items])
+        out[f"{tag}_index"] = obj_array([it[2] for it in items])
+        lab, msk, lens, idx = ref_dataloader.PhonemeOnlyCollater()(items[:8])
+        out[f"{tag}_c3_labels"], out[f"{tag}_c3_masked"] = lab.numpy(), msk.numpy()
+        out[f"{tag}_c3_lengths"] = np.array(lens)
+        out[f"{tag}_c3_index"] = obj_array(idx)
+        out[f"{tag}_c3_text_mask"] = ref_train.length_to_mask(torch.Tensor(lens)).numpy()
+        # --- 4-tuple stream (use_token_ids=True) --------------------------------------------------
+        np.random.seed(1)
+        random.seed(1)
+        ds4 = ref_dataloader.MaskedPhonemeDataset(data4, max_seq_length=msl, use_token_ids=True, **DATASET_PARAMS)
+        items4 = [ds4[i] for i in order[:8]]
+        tok, lab, msk, lens, idx = ref_dataloader.Collater()(items4)
+        out[f"{tag}_c4_tokens"], out[f"{tag}_c4_labels"], out[f"{tag}_c4_masked"] = tok.numpy(), lab.numpy(), msk.numpy()
+        out[f"{tag}_c4_lengths"] = np.array(lens)
+        out[f"{tag}_c4_index"] = obj_array(idx)
+    out["docs"] = np.array(["\x1f".join(d) for d in docs], dtype=object)
+    out["token_ids"] = obj_array([r["token_ids"] for r in data4])
+    # SURVEY.md §3.3 known answer: 2-doc toy set, 4th __getitem__ call, max_seq_length 16
+    np.random.seed(1)
+    random.seed(1)
+    toy = [{"phonemes": ["aa", "bb", "cc", "dd", "ee", "ff", "gg", "hh"]}, {"phonemes": ["ab", "cd", "ef"]}]
+    ds = ref_dataloader.MaskedPhonemeDataset(toy, max_seq_length=16, use_token_ids=False, **DATASET_PARAMS)
+    calls = [1, 0, 1, 0]
+    its = [ds[i] for i in calls]
+    out["ka_calls"] = np.array(calls)
+    out["ka_labels"] = obj_array([i[0].numpy() for i in its])
+    out["ka_masked"] = obj_array([i[1].numpy() for i in its])
+    out["ka_index"] = obj_array([i[2] for i in its])
+    # train/val split order of build_dataloader (random.shuffle on the stdlib stream)
+    np.random.seed(1)
+    random.seed(1)
+    big = [{"phonemes": ["ab", "cd"]} for _ in range(50)]
+    tl, vl = ref_dataloader.build_dataloader(big, batch_size=4, device="cpu",
+                                             dataset_config=dict(max_seq_length=512, **DATASET_PARAMS),
+                                             use_token_ids=False)
+    out["split_train_indices"] = np.array(tl.dataset.indices)
+    out["split_val_indices"] = np.array(vl.dataset.indices)
+    np.savez_compressed(os.path.join(OUT, "masking.npz"), **out, allow_pickle=True)
+    print("masking.npz written")
+
+
+def build_reference(cfg_kwargs, num_phonemes, num_tokens, sd, attn="eager"):
+    hf_cfg = AlbertConfig(vocab_size=cfg_kwargs["vocab_size"], attn_implementation=attn,
+                          **{k: v for k, v in cfg_kwargs.items() if k != "vocab_size"})
+    enc = AlbertModel(hf_cfg)
+    if num_tokens:
+        m = ref_model.MultiTaskModel(enc, num_phonemes=num_phonemes, num_tokens=num_tokens,
+                                     hidden_size=cfg_kwargs["hidden_size"])
+    else:
+        m = ref_model.PhonemeOnlyModel(enc, num_phonemes=num_phonemes, hidden_size=cfg_kwargs["hidden_size"])
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    assert all("position_ids" in k or "token_type_ids" in k for k in missing), missing
+    return m
+
+
+class _Acc:
+    device = torch.device("cpu")
+
+
+def ragged_batch(B, S, lengths, seed, vocab_hi=185):
+    """Padded batch (sorted by length, zero padded) with explicit masked-index lists."""
+    rs = np.random.RandomState(seed)
+    labels = np.zeros((B, S), np.int64)
+    masked = np.zeros((B, S), np.int64)
+    idxs = []
+    for b, L in enumerate(lengths):
+        lab = rs.randint(1, vocab_hi, size=L)
+        msk = lab.copy()
+        n = max(1, L // 6)
+        idx = sorted(rs.choice(L, size=n, replace=False).tolist())
+        for i in idx[: max(1, (3 * n) // 4)]:
+            msk[i] = 185
+        labels[b, :L], masked[b, :L] = lab, msk
+        idxs.append(idx)
+    return labels, masked, list(lengths), idxs
+
+
+def capture_model(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, full, n_steps, lr=7e-5):
+    """Run reference forward / loss / backward / AdamW and store what the tests compare."""
+    pcfg = plbert_amd.AlbertConfig(**cfg_kwargs)
+    sd = plbert_amd.deterministic_state_dict(pcfg, num_phonemes, num_tokens, seed=seed)
+    labels, masked, lengths, idxs = batch
+    out = dict(labels=labels, masked=masked, lengths=np.array(lengths), index=obj_array(idxs),
+               seed=np.array(seed), num_phonemes=np.array(num_phonemes), num_tokens=np.array(num_tokens),
+               cfg_keys=np.array(list(cfg_kwargs.keys())), cfg_vals=np.array(list(cfg_kwargs.values())))
+
+    m = build_reference(cfg_kwargs, num_phonemes, num_tokens, sd)
+    m.train()
+    tl, tm = torch.from_numpy(labels), torch.from_numpy(masked)
+    text_mask = ref_train.length_to_mask(torch.Tensor(lengths))
+    am = (~text_mask).int()
+    with torch.no_grad():
+        pred = m(tm, attention_mask=am)
+        hidden = m.encoder(tm, attention_mask=am).last_hidden_state
+    if num_tokens:
+        pred, tok_pred = pred
+        out["token_logits"] = tok_pred.numpy() if full else tok_pred.numpy()[:, :4, :64]
+    # sdpa delta, for the record
+    m_sdpa = build_reference(cfg_kwargs, num_phonemes, num_tokens, sd, attn="sdpa")
+    with torch.no_grad():
+        p2 = m_sdpa(tm, attention_mask=am)
+        p2 = p2[0] if num_tokens else p2
+    valid = am.bool().numpy()
+    out["sdpa_max_abs_delta_valid_rows"] = np.array(np.abs(p2.numpy() - pred.numpy())[valid].max())
+
+    if not num_tokens:
+        # the training step of the reference: process_batch -> backward -> AdamW (train.py:350-357)
+        crit = torch.nn.CrossEntropyLoss()
+        opt = torch.optim.AdamW(m.parameters(), lr=lr)
+        losses = []
+        for step in range(n_steps):
+            loss = ref_train.process_batch(m, (tl, tm, lengths, idxs), crit, _Acc())
+            opt.zero_grad()
+            loss.backward()
+            if step == 0:
+                grads = {k: (p.grad.detach().numpy().copy() if p.grad is not None else None)
+                         for k, p in m.named_parameters()}
+            opt.step()
+            losses.append(float(loss.item()))
+        out["losses"] = np.array(losses, dtype=np.float64)
+        out["loss"] = np.array(losses[0], dtype=np.float64)
+        names = [k for k, g in grads.items() if g is not None]
+        out["grad_names"] = np.array(names)
+        out["grad_none_names"] = np.array([k for k, g in grads.items() if g is None])
+        out["grad_l2"] = np.array([np.sqrt((grads[k].astype(np.float64) ** 2).sum()) for k in names])
+        final = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+        out["final_param_l2"] = np.array([np.sqrt((final[k].astype(np.float64) ** 2).sum()) for k in sd])
+        out["param_names"] = np.array(list(sd.keys()))
+        if full:
+            for k in names:
+                out["grad/" + k] = grads[k]
+            for k in sd:
+                out["final/" + k] = final[k]
+        else:
+            rs = np.random.RandomState(99)
+            for k in names:
+                flat = grads[k].reshape(-1)
+                probe = rs.randint(0, flat.size, size=min(8, flat.size))
+                out["gprobe_idx/" + k] = probe
+                out["gprobe_val/" + k] = flat[probe]
+
+    if full:
+        out["logits"] = pred.numpy()
+        out["hidden"] = hidden.numpy()
+    else:
+        B, S = labels.shape
+        rs = np.random.RandomState(5)
+        pb = rs.randint(0, B, size=16)
+        ps = np.array([rs.randint(0, lengths[b]) for b in pb])
+        out["probe_b"], out["probe_s"] = pb, ps
+        out["probe_logits"] = pred.numpy()[pb, ps, :]
+        out["probe_hidden"] = hidden.numpy()[pb, ps, :]
+        out["logit_row_sums"] = pred.numpy().sum(-1)
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out, allow_pickle=True)
+    print(tag, "written; loss", out.get("loss"), "sdpa delta", out["sdpa_max_abs_delta_valid_rows"])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    gen_masking()
+    # (2a) tiny model of SURVEY.md §4: everything stored in full (oracle pinning)
+    tiny = dict(vocab_size=188, embedding_size=16, hidden_size=64, num_attention_heads=4,
+                intermediate_size=128, num_hidden_layers=2, max_position_embeddings=512)
+    capture_model("tiny_h64", tiny, 188, 0, ragged_batch(2, 16, [16, 11], seed=3), seed=21, full=True, n_steps=3,
+                  lr=1e-3)
+    capture_model("tiny_h64_multitask", tiny, 188, 40, ragged_batch(2, 16, [16, 11], seed=3), seed=21, full=True,
+                  n_steps=0)
+    # (2b) smallest shape the HIP kernels accept (head_dim 64): full tensors, ragged lengths
+    small = dict(vocab_size=188, embedding_size=64, hidden_size=128, num_attention_heads=2,
+                 intermediate_size=256, num_hidden_layers=2, max_position_embeddings=512)
+    capture_model("small_h128", small, 188, 0, ragged_batch(3, 40, [40, 33, 7], seed=4), seed=22, full=True,
+                  n_steps=3, lr=1e-3)
+    capture_model("small_h128_multitask", small, 188, 96, ragged_batch(3, 40, [40, 33, 7], seed=4), seed=22,
+                  full=True, n_steps=0)
+    # (3) the real 768/12 model (configs/config.yml:32-39); weights regenerated on both sides, not stored
+    real = dict(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                max_position_embeddings=512, num_hidden_layers=12)
+    lab, msk, lens, idx = plbert_amd.synthetic_batch(8, 128, seed=1234)
+    capture_model("real_s128_b8", real, 188, 0, (lab, msk, lens, idx), seed=23, full=False, n_steps=5)
+    capture_model("real_s512_b2_ragged", real, 188, 0, ragged_batch(2, 512, [512, 300], seed=6), seed=23,
+                  full=False, n_steps=2)
+
+
+if __name__ == "__main__":
+    main()

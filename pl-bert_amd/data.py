@@ -1,0 +1,219 @@
+"""Host side of the masking / index path (SURVEY.md §8(a) rows A1–A3), bit-exact with the reference.
+
+Follows ``dataloader.py:19-142`` (MaskedPhonemeDataset), ``:200-223`` (Collater), ``:276-297``
+(PhonemeOnlyCollater), ``:225-274`` (build_dataloader) and ``train.py:34-44`` (length_to_mask).
+
+Bit-exactness depends on drawing from the SAME global generators in the SAME order as the
+reference: one ``np.random.rand()`` per word; for a selected word one ``np.random.choice`` over
+(mask, replace, keep); for a replaced word ``len(word)`` draws of the stdlib ``random`` stream; one
+``np.random.randint`` per cropped sample.  Like ``dataloader.py:16-17`` this module seeds both
+streams with 1 when imported.  Everything downstream of the decisions is integer work on id arrays.
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+
+from .symbols import CharacterIndexer, MASK_ID, SEPARATOR_ID
+
+
+def seed_reference_streams(seed=1):
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+seed_reference_streams(1)  # dataloader.py:16-17
+
+_ACTIONS = ("mask", "replace", "no_change")
+
+
+class MaskedPhonemeDataset(torch.utils.data.Dataset):
+    """Word-level mask / replace / keep over phoneme words (dataloader.py:19-142).
+
+    A row of ``dataset`` is ``{'phonemes': list[str]}`` (+ ``'token_ids'`` when ``use_token_ids``).
+    ``__getitem__`` returns ``(labels, masked, masked_index)`` or, with token ids,
+    ``(token_ids, labels, masked, masked_index)``; tensors are int64, ``masked_index`` a list.
+    """
+
+    def __init__(self, dataset, word_pred_prob, phoneme_mask_prob, replace_prob, word_separator,
+                 max_seq_length, use_token_ids):
+        self.data = dataset
+        self.max_seq_length = max_seq_length
+        self.word_pred_prob = word_pred_prob
+        self.phoneme_mask_prob = phoneme_mask_prob
+        self.replace_prob = replace_prob
+        self.char_indexer = CharacterIndexer()
+        self.word_separator = word_separator
+        self.use_token_ids = use_token_ids
+        # same float expression as dataloader.py:88 so the cumulative table is identical
+        self._probs = [phoneme_mask_prob, replace_prob, 1 - (phoneme_mask_prob + replace_prob)]
+
+    def __len__(self):
+        return len(self.data)
+
+    def _draw(self, words, pool_ids):
+        """Per-word decisions in reference RNG order -> (labels, masked, index) as id lists."""
+        index_word = self.char_indexer
+        labels, masked, index = [], [], []
+        n_pool = len(pool_ids)
+        for w in words:
+            ids = index_word(w)
+            n = len(ids)
+            start = len(masked)
+            labels.extend(ids)
+            labels.append(SEPARATOR_ID)
+            if np.random.rand() < self.word_pred_prob:                       # dataloader.py:85
+                action = _ACTIONS[int(np.random.choice(3, p=self._probs))]  # dataloader.py:89
+                if action == "replace":
+                    # random.choices(pool, k=n) draws floor(random() * len(pool)) n times (dataloader.py:94)
+                    picks = random.choices(range(n_pool), k=n) if n else []
+                    masked.extend(pool_ids[i] for i in picks)
+                elif action == "mask":
+                    masked.extend([MASK_ID] * n)
+                else:
+                    masked.extend(ids)
+                if action != "no_change":
+                    index.extend(range(start, start + n))                    # separator never indexed
+            else:
+                masked.extend(ids)
+            masked.append(SEPARATOR_ID)
+        return labels, masked, index
+
+    def __getitem__(self, idx):
+        row = self.data[idx]
+        words = row["phonemes"]
+        pool_ids = self.char_indexer("".join(words))  # replacement pool: the document itself
+        tok = row["token_ids"] if self.use_token_ids else [self.word_separator] * len(words)
+
+        labels, masked, index = self._draw(words, pool_ids)
+        token_ids = []
+        for w, t in zip(words, tok):
+            token_ids.extend([t] * len(w))
+            token_ids.append(self.word_separator)
+
+        n = len(masked)
+        if n > self.max_seq_length:                                         # dataloader.py:110-126
+            start = int(np.random.randint(0, n - self.max_seq_length))
+            end = start + self.max_seq_length
+            masked, token_ids, labels = masked[start:end], token_ids[start:end], labels[start:end]
+            index = [i - start for i in index if start <= i < end]
+
+        masked_t = torch.LongTensor(masked)
+        labels_t = torch.LongTensor(labels)
+        token_t = torch.LongTensor(token_ids)
+        assert len(masked_t) == len(token_t) == len(labels_t)
+        if self.use_token_ids:
+            return token_t, labels_t, masked_t, index
+        return labels_t, masked_t, index
+
+
+def _pad_stack(rows, width):
+    out = torch.zeros((len(rows), width), dtype=torch.long)  # pad id 0 = 'P'
+    for i, r in enumerate(rows):
+        out[i, : r.shape[0]] = r
+    return out
+
+
+class PhonemeOnlyCollater:
+    """Length-descending sort + zero pad to the batch maximum (dataloader.py:276-297)."""
+
+    def __call__(self, batch):
+        batch = sorted(batch, key=lambda x: x[0].shape[0], reverse=True)
+        width = batch[0][0].shape[0]
+        labels = _pad_stack([b[0] for b in batch], width)
+        masked = _pad_stack([b[1] for b in batch], width)
+        lengths = [int(b[1].shape[0]) for b in batch]
+        indices = [b[2] for b in batch]
+        return labels, masked, lengths, indices
+
+
+class Collater:
+    """4-tuple form with token ids (dataloader.py:200-223)."""
+
+    def __call__(self, batch):
+        batch = sorted(batch, key=lambda x: x[0].shape[0], reverse=True)
+        width = batch[0][0].shape[0]
+        tokens = _pad_stack([b[0] for b in batch], width)
+        labels = _pad_stack([b[1] for b in batch], width)
+        masked = _pad_stack([b[2] for b in batch], width)
+        lengths = [int(b[2].shape[0]) for b in batch]
+        indices = [b[3] for b in batch]
+        return tokens, labels, masked, lengths, indices
+
+
+def build_dataloader(df, batch_size, device, dataset_config, use_token_ids, num_workers=0, **kwargs):
+    """95/5 train/val split by ``random.shuffle`` then two DataLoaders (dataloader.py:225-274)."""
+    from torch.utils.data import DataLoader, Subset
+
+    dataset = MaskedPhonemeDataset(df, use_token_ids=use_token_ids, **dataset_config)
+    total = len(dataset)
+    val_size = min(int(total * 0.05), 10000)
+    order = list(range(total))
+    random.shuffle(order)
+    train_set = Subset(dataset, order[: total - val_size])
+    val_set = Subset(dataset, order[total - val_size:])
+    collate = Collater() if use_token_ids else PhonemeOnlyCollater()
+    pin = device != "cpu"
+    train_loader = DataLoader(train_set, batch_size=batch_size, shuffle=True, drop_last=True,
+                              collate_fn=collate, pin_memory=pin, num_workers=num_workers, **kwargs)
+    val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, drop_last=False,
+                            collate_fn=collate, pin_memory=pin, num_workers=num_workers, **kwargs)
+    return train_loader, val_loader
+
+
+def length_to_mask(lengths):
+    """train.py:34-44 — bool [B, max_len], True on PAD: (position + 1) > length."""
+    lengths = torch.as_tensor(lengths)
+    width = int(lengths.max().item())
+    pos = torch.arange(width, device=lengths.device).expand(lengths.size(0), width)
+    return (pos + 1) > lengths.unsqueeze(1)
+
+
+def masked_indices_to_csr(masked_indices):
+    """list[list[int]] -> (offsets int32 [B+1], flat int32 [n]) for the device loss kernels."""
+    offsets = np.zeros(len(masked_indices) + 1, dtype=np.int32)
+    for b, idx in enumerate(masked_indices):
+        offsets[b + 1] = offsets[b] + len(idx)
+    flat = np.fromiter((i for idx in masked_indices for i in idx), dtype=np.int32, count=int(offsets[-1]))
+    return offsets, flat
+
+
+def synthetic_batch(batch_size, seq_len, seed, word_pred_prob=0.15, phoneme_mask_prob=0.8, replace_prob=0.1):
+    """Fixed-length synthetic batch of SURVEY.md §8(d): ids uniform over 1..184, words of length
+    3..7 closed by the separator 186, word-level masking with the reference probabilities, every
+    sample guaranteed at least one masked index.  Own RandomState: global streams untouched."""
+    rs = np.random.RandomState(seed)
+    labels = np.zeros((batch_size, seq_len), dtype=np.int64)
+    masked = np.zeros((batch_size, seq_len), dtype=np.int64)
+    indices = []
+    cdf = np.cumsum([phoneme_mask_prob, replace_prob, 1 - (phoneme_mask_prob + replace_prob)])
+    for b in range(batch_size):
+        lab = rs.randint(1, 185, size=seq_len).astype(np.int64)
+        bounds, pos = [], 0
+        while pos < seq_len:
+            n = int(rs.randint(3, 8))
+            end = min(pos + n, seq_len)
+            bounds.append((pos, end))
+            if end < seq_len:
+                lab[end] = SEPARATOR_ID
+            pos = end + 1
+        msk = lab.copy()
+        idx = []
+        for (s, e) in bounds:
+            if rs.rand() < word_pred_prob:
+                a = int(np.searchsorted(cdf, rs.rand(), side="right"))
+                if a == 0:
+                    msk[s:e] = MASK_ID
+                elif a == 1:
+                    msk[s:e] = lab[rs.randint(0, seq_len, size=e - s)]
+                if a != 2:
+                    idx.extend(range(s, e))
+        if not idx:
+            s, e = bounds[0]
+            msk[s:e] = MASK_ID
+            idx = list(range(s, e))
+        labels[b], masked[b] = lab, msk
+        indices.append(idx)
+    return labels, masked, [seq_len] * batch_size, indices

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=True)
+
+
+def golden_cfg(g):
+    """(oracle Config, product AlbertConfig kwargs, state dict) from a model fixture."""
+    from oracle.albert_np import Config
+    import plbert_amd
+
+    kw = {k: int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    pcfg = plbert_amd.AlbertConfig(**kw)
+    nph, ntok = int(g["num_phonemes"]), int(g["num_tokens"])
+    sd = plbert_amd.deterministic_state_dict(pcfg, nph, ntok, seed=int(g["seed"]))
+    ocfg = Config(vocab_size=pcfg.vocab_size, embedding_size=pcfg.embedding_size, hidden_size=pcfg.hidden_size,
+                  num_attention_heads=pcfg.num_attention_heads, intermediate_size=pcfg.intermediate_size,
+                  num_hidden_layers=pcfg.num_hidden_layers, num_phonemes=nph, num_tokens=ntok)
+    return ocfg, pcfg, sd
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return GOLDEN
