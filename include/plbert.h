@@ -1,0 +1,129 @@
+/* plbert.h — C ABI of the MI355X-native PL-BERT pre-training hot path (libplbert_hip.so).
+ *
+ * The reference (Fadi987/PL-BERT) has no FFI: its boundary for this path is a Python nn.Module
+ * contract.  Each entry point below names the reference interface it stands in
+ * for; the Python host in pl-bert_amd/ (model.py, engine.py) binds them with ctypes and mirrors the
+ * reference classes on top.  Plain pointers and sizes only: device pointers are raw HBM addresses
+ * (any allocator — the Python host passes torch tensors' data_ptr()), `stream` is a hipStream_t
+ * passed as void* (NULL = the legacy default stream).  Every call is asynchronous on `stream`
+ * unless stated otherwise.  Return value: 0 = ok, non-zero = error, text via plb_last_error().
+ * One engine serves one GPU and one host thread at a time (the reference runs one process per
+ * GPU with a single-threaded step loop, train.py:350-357).
+ */
+#ifndef PLBERT_H
+#define PLBERT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct PlbEngine PlbEngine;
+
+/* The AlbertConfig subset of the path (train.py:263-265; configs/config.yml:32-39; HF defaults
+ * configuration_albert.py:56-75) plus the head sizes (model.py:6,20) and workspace capacity. */
+typedef struct {
+  int32_t vocab_size;              /* len(symbols) = 188 (train.py:263) */
+  int32_t embedding_size;          /* 128 */
+  int32_t hidden_size;             /* 768 */
+  int32_t num_attention_heads;     /* 12; hidden_size / heads must be 64 */
+  int32_t intermediate_size;       /* 2048 */
+  int32_t num_hidden_layers;       /* 12 applications of the one shared layer */
+  int32_t max_position_embeddings; /* 512 */
+  int32_t type_vocab_size;         /* 2 */
+  float layer_norm_eps;            /* 1e-12 */
+  int32_t num_phonemes;            /* phoneme_predictor out features (model.py:10,24) */
+  int32_t num_tokens;              /* token_predictor out features, 0 = PhonemeOnlyModel (model.py:11) */
+  int32_t max_batch;               /* capacity: largest B accepted by the calls below */
+  int32_t max_seq;                 /* capacity: largest S (<= max_position_embeddings) */
+} PlbConfig;
+
+/* Parameter tensors in flat-buffer order; names follow the reference state_dict.
+ * query/key/value weights (and biases) are adjacent so they form the fused [3H,H] QKV operand. */
+enum PlbParam {
+  PLB_WORD_EMB = 0,   /* encoder.embeddings.word_embeddings.weight        [V,E]  */
+  PLB_POS_EMB,        /* encoder.embeddings.position_embeddings.weight    [P,E]  */
+  PLB_TYPE_EMB,       /* encoder.embeddings.token_type_embeddings.weight  [2,E]  */
+  PLB_EMB_LN_W,       /* encoder.embeddings.LayerNorm.weight              [E]    */
+  PLB_EMB_LN_B,       /* encoder.embeddings.LayerNorm.bias                [E]    */
+  PLB_MAP_W,          /* encoder.encoder.embedding_hidden_mapping_in.weight [H,E] */
+  PLB_MAP_B,          /* ...embedding_hidden_mapping_in.bias              [H]    */
+  PLB_LN2_W,          /* <layer>.full_layer_layer_norm.weight             [H]    */
+  PLB_LN2_B,          /* <layer>.full_layer_layer_norm.bias               [H]    */
+  PLB_Q_W, PLB_K_W, PLB_V_W,   /* <layer>.attention.{query,key,value}.weight [H,H] each */
+  PLB_Q_B, PLB_K_B, PLB_V_B,   /* <layer>.attention.{query,key,value}.bias   [H] each   */
+  PLB_DENSE_W,        /* <layer>.attention.dense.weight                   [H,H]  */
+  PLB_DENSE_B,        /* <layer>.attention.dense.bias                     [H]    */
+  PLB_LN1_W,          /* <layer>.attention.LayerNorm.weight               [H]    */
+  PLB_LN1_B,          /* <layer>.attention.LayerNorm.bias                 [H]    */
+  PLB_FFN_W,          /* <layer>.ffn.weight                               [I,H]  */
+  PLB_FFN_B,          /* <layer>.ffn.bias                                 [I]    */
+  PLB_FFNO_W,         /* <layer>.ffn_output.weight                        [H,I]  */
+  PLB_FFNO_B,         /* <layer>.ffn_output.bias                          [H]    */
+  PLB_HEAD_W,         /* phoneme_predictor.weight                         [NP,H] */
+  PLB_HEAD_B,         /* phoneme_predictor.bias                           [NP]   */
+  /* --- everything below receives no gradient in the reference (train.py:383-390 never reads it) */
+  PLB_POOL_W,         /* encoder.pooler.weight                            [H,H]  */
+  PLB_POOL_B,         /* encoder.pooler.bias                              [H]    */
+  PLB_TOK_W,          /* token_predictor.weight                           [NT,H] (size 0 when num_tokens = 0) */
+  PLB_TOK_B,          /* token_predictor.bias                             [NT]   */
+  PLB_NPARAM
+};
+
+/* Thread-local text of the last error returned by any call on this thread. */
+const char* plb_last_error(void);
+
+/* Stands in for: AlbertModel(AlbertConfig(...)) + PhonemeOnlyModel/MultiTaskModel construction
+ * (train.py:263-270; model.py:6-11,20-24). Host-only; allocates no device memory. */
+int plb_create(const PlbConfig* cfg, PlbEngine** out);
+void plb_destroy(PlbEngine* e);
+
+/* Flat parameter layout: offsets/sizes in floats for each PlbParam, the total float count and the
+ * count of leading floats that receive gradients (AdamW range). Stands in for
+ * nn.Module.parameters()/state_dict() (train.py:272,417). Arrays hold PLB_NPARAM entries. */
+int plb_param_layout(const PlbEngine* e, int64_t* offsets, int64_t* sizes, int64_t* total, int64_t* trainable);
+
+/* Bytes of device workspace the engine needs for its capacity (activations stashed for all
+ * layers, bf16 weight copies, split-K slabs). The caller allocates it ZERO-FILLED. */
+int64_t plb_workspace_bytes(const PlbEngine* e);
+
+/* Borrow the caller's device buffers: fp32 params / grads / AdamW moments (each `total` floats,
+ * laid out per plb_param_layout; grads and moments may be NULL for inference-only use) and the
+ * workspace. Stands in for module.to(device) / accelerator.prepare (train.py:160-162). */
+int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* workspace,
+             int64_t workspace_bytes);
+
+/* Refresh the bf16 (and transposed) compute copies from the fp32 parameters. Call after the
+ * parameters were written from outside (load_state_dict, train.py:100; broadcast at start-up).
+ * plb_adamw_step does this itself. */
+int plb_sync_weights(PlbEngine* e, void* stream);
+
+/* Stands in for PhonemeOnlyModel.forward / MultiTaskModel.forward / AlbertModel.forward
+ * (model.py:13-18,26-30; train.py:386; README.md:91): ids int64 [B,S]; lengths int32 [B] = number
+ * of valid (attention_mask == 1) leading tokens per sample, or NULL for no padding. Any of the
+ * outputs may be NULL: hidden fp32 [B,S,H] (.last_hidden_state), phoneme_logits fp32 [B,S,NP],
+ * token_logits fp32 [B,S,NT]. */
+int plb_forward(PlbEngine* e, const int64_t* ids, const int32_t* lengths, int32_t B, int32_t S, float* hidden,
+                float* phoneme_logits, float* token_logits, void* stream);
+
+/* Stands in for process_batch + calculate_phoneme_loss + accelerator.backward (train.py:381-390,
+ * 107-131, 356): masked_ids/labels int64 [B,S]; lengths int32 [B]; the per-sample masked index
+ * lists as CSR (idx_offsets int32 [B+1], idx_flat int32 [n_masked], positions < lengths[b], unique
+ * within a sample). Writes the scalar loss (fp32, device) and the gradient of every trainable
+ * parameter into the bound grads buffer (overwritten, not accumulated). n_masked == 0 reproduces
+ * the reference's zero-loss fallback: loss 0 and all gradients 0. */
+int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int32_t* lengths,
+                     const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked, int32_t B, int32_t S,
+                     float* loss, void* stream);
+
+/* Stands in for torch.optim.AdamW.step (train.py:272,357): decoupled weight decay on every
+ * trainable parameter, bias-corrected moments; `step` counts from 1; gradients are multiplied by
+ * grad_scale first (1/world_size after a sum all-reduce). Also refreshes the bf16 copies. */
+int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                   float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLBERT_H */

@@ -1,0 +1,169 @@
+"""ctypes binding of libplbert_hip.so — the C ABI declared in include/plbert.h.
+
+There is no CPU fallback: if the library is missing or fails to load, every entry point of the
+product path raises.  torch is imported first so the library resolves HIP against the same
+libamdhip64 torch already mapped (one HIP runtime per process; torch's stream handles are then
+valid in our launches).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL: see module docstring)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libplbert_hip.so")
+
+PLB_PARAM_NAMES = [
+    "encoder.embeddings.word_embeddings.weight",
+    "encoder.embeddings.position_embeddings.weight",
+    "encoder.embeddings.token_type_embeddings.weight",
+    "encoder.embeddings.LayerNorm.weight",
+    "encoder.embeddings.LayerNorm.bias",
+    "encoder.encoder.embedding_hidden_mapping_in.weight",
+    "encoder.encoder.embedding_hidden_mapping_in.bias",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.full_layer_layer_norm.weight",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.full_layer_layer_norm.bias",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.attention.query.weight",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.attention.key.weight",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.attention.value.weight",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.attention.query.bias",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.attention.key.bias",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.attention.value.bias",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.attention.dense.weight",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.attention.dense.bias",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.attention.LayerNorm.weight",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.attention.LayerNorm.bias",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.ffn.weight",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.ffn.bias",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.ffn_output.weight",
+    "encoder.encoder.albert_layer_groups.0.albert_layers.0.ffn_output.bias",
+    "phoneme_predictor.weight",
+    "phoneme_predictor.bias",
+    "encoder.pooler.weight",
+    "encoder.pooler.bias",
+    "token_predictor.weight",
+    "token_predictor.bias",
+]
+PLB_NPARAM = len(PLB_PARAM_NAMES)
+
+# every symbol include/plbert.h declares (tests check the library exports all of them)
+PUBLIC_SYMBOLS = [
+    "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
+    "plb_sync_weights", "plb_forward", "plb_loss_fwd_bwd", "plb_adamw_step",
+]
+
+
+class PlbConfig(C.Structure):
+    _fields_ = [
+        ("vocab_size", C.c_int32), ("embedding_size", C.c_int32), ("hidden_size", C.c_int32),
+        ("num_attention_heads", C.c_int32), ("intermediate_size", C.c_int32), ("num_hidden_layers", C.c_int32),
+        ("max_position_embeddings", C.c_int32), ("type_vocab_size", C.c_int32), ("layer_norm_eps", C.c_float),
+        ("num_phonemes", C.c_int32), ("num_tokens", C.c_int32), ("max_batch", C.c_int32), ("max_seq", C.c_int32),
+    ]
+
+
+# ---- internal launch structs (csrc/plbert_kernels.h) — used by the kernel-level GPU tests ------------
+class PlbGemmNT(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("Mstore", C.c_int),
+        ("bias", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_int), ("aux", C.c_void_p), ("ldaux", C.c_int),
+        ("C", C.c_void_p), ("ldc", C.c_int), ("C2", C.c_void_p), ("ldc2", C.c_int), ("Cf", C.c_void_p), ("ldcf", C.c_int),
+    ]
+
+
+class PlbGemmTN(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int), ("Ncols", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int),
+        ("Mtot", C.c_int), ("N", C.c_int), ("K", C.c_int), ("rows_per_split", C.c_int), ("splits", C.c_int),
+        ("slab", C.c_void_p),
+    ]
+
+
+class PlbAttn(C.Structure):
+    _fields_ = [
+        ("qkv", C.c_void_p), ("ldqkv", C.c_int), ("lengths", C.c_void_p),
+        ("B", C.c_int), ("S", C.c_int), ("NH", C.c_int), ("H", C.c_int), ("scale", C.c_float),
+        ("ctx", C.c_void_p), ("ldctx", C.c_int), ("lse", C.c_void_p),
+        ("dctx", C.c_void_p), ("lddctx", C.c_int), ("delta", C.c_void_p), ("dqkv", C.c_void_p), ("lddqkv", C.c_int),
+    ]
+
+
+class PlbLayerNorm(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float),
+        ("y", C.c_void_p), ("ldy", C.c_int), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+        ("T", C.c_int), ("H", C.c_int), ("Tzero", C.c_int),
+        ("dy", C.c_void_p), ("lddy", C.c_int), ("dx", C.c_void_p), ("lddx", C.c_int),
+        ("partials", C.c_void_p), ("nblocks", C.c_int),
+    ]
+
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises HipLibraryMissing (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} is missing: build it with `python -m plbert_amd.build` (needs hipcc, gfx950). "
+            "There is no CPU fallback for the PL-BERT hot path.")
+    try:
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    except OSError as ex:
+        raise HipLibraryMissing(f"cannot load {LIB_PATH}: {ex}") from ex
+    vp, i32, i64p, f32 = C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_float
+    L.plb_last_error.restype = C.c_char_p
+    L.plb_last_error.argtypes = []
+    L.plb_create.restype = C.c_int
+    L.plb_create.argtypes = [C.POINTER(PlbConfig), C.POINTER(vp)]
+    L.plb_destroy.restype = None
+    L.plb_destroy.argtypes = [vp]
+    L.plb_param_layout.restype = C.c_int
+    L.plb_param_layout.argtypes = [vp, i64p, i64p, i64p, i64p]
+    L.plb_workspace_bytes.restype = C.c_int64
+    L.plb_workspace_bytes.argtypes = [vp]
+    L.plb_bind.restype = C.c_int
+    L.plb_bind.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64]
+    L.plb_sync_weights.restype = C.c_int
+    L.plb_sync_weights.argtypes = [vp, vp]
+    L.plb_forward.restype = C.c_int
+    L.plb_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.plb_loss_fwd_bwd.restype = C.c_int
+    L.plb_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.plb_adamw_step.restype = C.c_int
+    L.plb_adamw_step.argtypes = [vp, f32, f32, f32, f32, f32, i32, f32, vp]
+    # internal launchers (kernel-level tests)
+    L.plb_launch_gemm_nt.restype = C.c_int
+    L.plb_launch_gemm_nt.argtypes = [C.POINTER(PlbGemmNT), C.c_int, C.c_int, vp]
+    L.plb_launch_gemm_tn.restype = C.c_int
+    L.plb_launch_gemm_tn.argtypes = [C.POINTER(PlbGemmTN), vp]
+    L.plb_launch_reduce_slabs.restype = C.c_int
+    L.plb_launch_reduce_slabs.argtypes = [vp, C.c_int, C.c_size_t, vp, C.c_int, vp]
+    L.plb_launch_attn_fwd.restype = C.c_int
+    L.plb_launch_attn_fwd.argtypes = [C.POINTER(PlbAttn), vp]
+    L.plb_launch_attn_bwd.restype = C.c_int
+    L.plb_launch_attn_bwd.argtypes = [C.POINTER(PlbAttn), vp]
+    L.plb_launch_ln_fwd.restype = C.c_int
+    L.plb_launch_ln_fwd.argtypes = [C.POINTER(PlbLayerNorm), vp]
+    L.plb_launch_ln_bwd.restype = C.c_int
+    L.plb_launch_ln_bwd.argtypes = [C.POINTER(PlbLayerNorm), vp]
+    L.plb_launch_colsum.restype = C.c_int
+    L.plb_launch_colsum.argtypes = [vp, C.c_int, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().plb_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed: {msg or 'rc=%d' % rc}")

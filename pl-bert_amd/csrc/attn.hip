@@ -1,0 +1,434 @@
+// Fused multi-head attention for the shared ALBERT layer, head_dim 64, gfx950.
+// Restates AlbertAttention's softmax(q·k^T·d^-0.5 + key_padding_mask)·v (modeling_albert.py:110-135,
+// 166-200) as a flash-style single pass: scores never leave registers.
+//
+// Forward, one workgroup = 4 waves = 128 query rows of one (batch, head); a wave owns 32 queries.
+//   S^T[key][q] = K·Q^T  (MFMA 32x32x16, K rows from LDS, Q fragments in registers) puts one query
+//   per lane, so the row max / row sum are lane-local (+ one exchange with lane^32).  The S^T
+//   accumulator converted to bf16 is directly the B operand of O^T[dv][q] = V^T·P^T (accumulator-as-
+//   operand, k order 16s+8(j>>2)+4h+(j&3)); V^T fragments come from ds_read_b64_tr_b16 on a
+//   [4 keys][32 dv] sub-tiled LDS image (each half-wave read = one 256-B bank row).
+// Backward, two kernels that recompute P from the saved log-sum-exp:
+//   dq kernel  (same tiling as forward): dS^T = P^T∘(dP^T - delta), dQ^T = K^T·dS^T ; also writes delta.
+//   dkv kernel (a wave owns 32 keys, loops over query tiles): dV^T = dO^T·P, dK^T = Q^T·dS.
+// Key padding comes from lengths[b]; whole key tiles past the length are skipped.
+#include "common.h"
+#include "plbert_kernels.h"
+
+namespace {
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+// [64 rows][64 cols] bf16, 128-B rows, chunk index XORed with (row>>1)&7: conflict-free ds_read_b128
+// for 32 consecutive rows at one chunk.
+DEVI int row_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 1) & 7)) << 3); }
+// [64 rows][64 cols] bf16 in [row/4][col/32][4][32] sub-tiles of 256 B: conflict-free tr reads.
+DEVI int tr_off(int row, int col) { return (((row >> 2) << 1) + (col >> 5)) * 128 + (row & 3) * 32 + (col & 31); }
+
+// A-operand fragment of X^T (X stored [row][col] in the tr layout): lane (m = cb*32 + (l&31), half h)
+// element j <- X[rb*32 + 16s + 8(j>>2) + 4h + (j&3)][m]
+DEVI bf16x8 tr_frag(const bf16_t* tile, int rb, int s, int cb, int lane) {
+  const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3, h = g >> 1;
+  const int r0 = rb * 32 + 16 * s + 4 * h + q4;
+  const int c = cb * 32 + 16 * (g & 1) + 4 * p4;
+  s16x4 a = lds_read_tr16(&tile[tr_off(r0, c)]);
+  s16x4 b = lds_read_tr16(&tile[tr_off(r0 + 8, c)]);
+  return bf16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+// Row-layout fragment: lane (row = rb*32 + (l&31), k = ks*16 + 8h + j)
+DEVI bf16x8 row_frag(const bf16_t* tile, int rb, int ks, int lane) {
+  const int row = rb * 32 + (lane & 31);
+  return *(const bf16x8*)&tile[row_off(row, ks * 2 + (lane >> 5))];
+}
+// registers 8s..8s+7 of a 32x32 accumulator -> bf16x8 operand fragment (k-step s)
+DEVI bf16x8 acc_frag(const f32x16& x, int s) {
+  bf16x8 r;
+  uint32_t u0 = pack_bf2(x[8 * s + 0], x[8 * s + 1]), u1 = pack_bf2(x[8 * s + 2], x[8 * s + 3]);
+  uint32_t u2 = pack_bf2(x[8 * s + 4], x[8 * s + 5]), u3 = pack_bf2(x[8 * s + 6], x[8 * s + 7]);
+  r[0] = (short)(u0 & 0xFFFF); r[1] = (short)(u0 >> 16); r[2] = (short)(u1 & 0xFFFF); r[3] = (short)(u1 >> 16);
+  r[4] = (short)(u2 & 0xFFFF); r[5] = (short)(u2 >> 16); r[6] = (short)(u3 & 0xFFFF); r[7] = (short)(u3 >> 16);
+  return r;
+}
+DEVI f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// Store a wave's transposed accumulator pair X^T[64 c][32 r] (lane = r, registers = c) as rows
+// out[r][0..63] (bf16) through a per-wave LDS patch with 144-B rows, then 16-B coalesced stores.
+DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_t* patch, bf16_t* gout, int ldo,
+                           int rows_valid, int lane) {
+  constexpr int PS = 72;  // elements per patch row (144 B)
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const f32x16& a = cb ? a1 : a0;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      uint2 v;
+      v.x = pack_bf2(a[4 * rg + 0] * mult, a[4 * rg + 1] * mult);
+      v.y = pack_bf2(a[4 * rg + 2] * mult, a[4 * rg + 3] * mult);
+      *(uint2*)&patch[r * PS + cb * 32 + 8 * rg + 4 * h] = v;
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the patch is private to this wave
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = lane + 64 * i, row = id >> 3, c = id & 7;
+    uint4 v = *(const uint4*)&patch[row * PS + c * 8];
+    if (row < rows_valid) *(uint4*)(gout + (size_t)row * ldo + c * 8) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------- forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(PlbAttn p) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][64 * 64];  // [stage][K row | V tr] 32 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int S = p.S, H = p.H;
+  int len = p.lengths ? p.lengths[b] : S;
+  len = len < 1 ? 1 : (len > S ? S : len);
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const size_t tok0 = (size_t)b * S;
+  const bf16_t* qbase = p.qkv + hd * 64;
+  const bf16_t* kbase = p.qkv + H + hd * 64;
+  const bf16_t* vbase = p.qkv + 2 * H + hd * 64;
+  const int ld = p.ldqkv;
+  const int lq = lane & 31, h = lane >> 5;
+
+  bf16x8 qf[4];
+  {
+    int qr = q0 + lq; qr = qr < S ? qr : S - 1;
+    const bf16_t* qp = qbase + (tok0 + qr) * ld + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+  }
+
+  const int nkt = (len + 63) >> 6;
+  const int sr = tid >> 3, sc = tid & 7;  // staging: 32 rows x 8 chunks, 2 passes
+  uint4 kr[2], vr[2];
+  auto load_kv = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = kt * 64 + sr + 32 * i; key = key < S ? key : S - 1;
+      kr[i] = *(const uint4*)(kbase + (tok0 + key) * ld + sc * 8);
+      vr[i] = *(const uint4*)(vbase + (tok0 + key) * ld + sc * 8);
+    }
+  };
+  auto store_kv = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = sr + 32 * i;
+      *(uint4*)&smem[st][0][row_off(r, sc)] = kr[i];
+      *(uint4*)&smem[st][1][tr_off(r, sc * 8)] = vr[i];
+    }
+  };
+
+  f32x16 o0 = zero16(), o1 = zero16();
+  float m_run = -INFINITY, l_run = 0.f;
+  const float sl2 = p.scale * LOG2E;
+
+  load_kv(0);
+  store_kv(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) load_kv(kt + 1);
+    const bf16_t* sK = smem[cur][0];
+    const bf16_t* sV = smem[cur][1];
+    f32x16 s0 = zero16(), s1 = zero16();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, 0, ks, lane), qf[ks], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, 1, ks, lane), qf[ks], s1, 0, 0, 0);
+    }
+    // scale into the exp2 domain, mask padded keys, tile max for this lane's query
+    const int kbase_i = kt * 64 + 4 * h;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kr0 = kbase_i + (r & 3) + 8 * (r >> 2);
+      s0[r] = (kr0 < len) ? s0[r] * sl2 : -INFINITY;
+      s1[r] = (kr0 + 32 < len) ? s1[r] * sl2 : -INFINITY;
+      mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);   // finite: the first tile always holds key 0 < len
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+      s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+      ls += s0[r] + s1[r];
+    }
+    l_run = l_run * alpha + ls;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const bf16x8 pb = acc_frag((s4 >> 1) ? s1 : s0, s4 & 1);
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, s4 >> 1, s4 & 1, 0, lane), pb, o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, s4 >> 1, s4 & 1, 1, lane), pb, o1, 0, 0, 0);
+    }
+    if (kt + 1 < nkt) store_kv(cur ^ 1);
+    __syncthreads();
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (h == 0 && q0 + lq < S)
+    p.lse[((size_t)b * p.NH + hd) * S + q0 + lq] = m_run * LN2 + __logf(l_tot);
+  // all waves are past the last barrier: reuse the staging LDS as per-wave transpose patches
+  bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
+  int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
+  if (rows_valid > 0)
+    store_transposed(o0, o1, inv, patch, p.ctx + (tok0 + q0) * p.ldctx + hd * 64, p.ldctx, rows_valid, lane);
+}
+
+// ------------------------------------------------------------------------------------- backward dQ
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(PlbAttn p) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2][3][64 * 64];  // [stage][K row | K tr | V row] 48 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int S = p.S, H = p.H;
+  int len = p.lengths ? p.lengths[b] : S;
+  len = len < 1 ? 1 : (len > S ? S : len);
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const size_t tok0 = (size_t)b * S;
+  const bf16_t* kbase = p.qkv + H + hd * 64;
+  const bf16_t* vbase = p.qkv + 2 * H + hd * 64;
+  const int ld = p.ldqkv;
+  const int lq = lane & 31, h = lane >> 5;
+  int qr = q0 + lq; qr = qr < S ? qr : S - 1;
+
+  bf16x8 qf[4], dof[4];
+  float delta;
+  {
+    const bf16_t* qp = p.qkv + hd * 64 + (tok0 + qr) * ld + 8 * h;
+    const bf16_t* dop = p.dctx + (tok0 + qr) * p.lddctx + hd * 64 + 8 * h;
+    const bf16_t* op = p.ctx + (tok0 + qr) * p.ldctx + hd * 64 + 8 * h;
+    float d = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      qf[ks] = *(const bf16x8*)(qp + ks * 16);
+      dof[ks] = *(const bf16x8*)(dop + ks * 16);
+      bf16x8 of = *(const bf16x8*)(op + ks * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += bf2f((bf16_t)dof[ks][j]) * bf2f((bf16_t)of[j]);
+    }
+    delta = d + __shfl_xor(d, 32, 64);
+  }
+  const size_t stat = ((size_t)b * p.NH + hd) * S + qr;
+  if (h == 0 && q0 + lq < S) p.delta[stat] = delta;
+  const float lse2 = p.lse[stat] * LOG2E;
+  const float sl2 = p.scale * LOG2E;
+
+  const int nkt = (len + 63) >> 6;
+  const int sr = tid >> 3, sc = tid & 7;
+  uint4 kr[2], vr[2];
+  auto load_kv = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int key = kt * 64 + sr + 32 * i; key = key < S ? key : S - 1;
+      kr[i] = *(const uint4*)(kbase + (tok0 + key) * ld + sc * 8);
+      vr[i] = *(const uint4*)(vbase + (tok0 + key) * ld + sc * 8);
+    }
+  };
+  auto store_kv = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = sr + 32 * i;
+      *(uint4*)&smem[st][0][row_off(r, sc)] = kr[i];
+      *(uint4*)&smem[st][1][tr_off(r, sc * 8)] = kr[i];
+      *(uint4*)&smem[st][2][row_off(r, sc)] = vr[i];
+    }
+  };
+
+  f32x16 dq0 = zero16(), dq1 = zero16();
+  load_kv(0);
+  store_kv(0);
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nkt) load_kv(kt + 1);
+    const bf16_t* sK = smem[cur][0];
+    const bf16_t* sKt = smem[cur][1];
+    const bf16_t* sV = smem[cur][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb, ks, lane), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, kb, ks, lane), dof[ks], dp, 0, 0, 0);
+      }
+      const int kb0 = kt * 64 + kb * 32 + 4 * h;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb0 + (r & 3) + 8 * (r >> 2);
+        const float pr = (key < len) ? __builtin_amdgcn_exp2f(s[r] * sl2 - lse2) : 0.f;
+        s[r] = pr * (dp[r] - delta);   // dS^T (scale applied once at the end)
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 dsb = acc_frag(s, s2);
+        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sKt, kb, s2, 0, lane), dsb, dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sKt, kb, s2, 1, lane), dsb, dq1, 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nkt) store_kv(cur ^ 1);
+    __syncthreads();
+  }
+  bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
+  int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
+  if (rows_valid > 0)
+    store_transposed(dq0, dq1, p.scale, patch, p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64, p.lddqkv, rows_valid, lane);
+}
+
+// ---------------------------------------------------------------------------------- backward dK,dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(PlbAttn p) {
+  // [stage][Q row | Q tr | dO row | dO tr] + lse/delta rows
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2][4][64 * 64];  // 64 KiB
+  __shared__ __attribute__((aligned(16))) float sstat[2][2][64];       // [stage][lse*log2e | delta][q]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int S = p.S, H = p.H;
+  int len = p.lengths ? p.lengths[b] : S;
+  len = len < 1 ? 1 : (len > S ? S : len);
+  const int key0 = blockIdx.x * 128 + wave * 32;
+  const size_t tok0 = (size_t)b * S;
+  const int ld = p.ldqkv;
+  const int lk = lane & 31, h = lane >> 5;
+  const int mykey = key0 + lk;
+
+  bf16x8 kf[4], vf[4];
+  {
+    int kr_ = mykey < S ? mykey : S - 1;
+    const bf16_t* kp = p.qkv + H + hd * 64 + (tok0 + kr_) * ld + 8 * h;
+    const bf16_t* vp = p.qkv + 2 * H + hd * 64 + (tok0 + kr_) * ld + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      kf[ks] = *(const bf16x8*)(kp + ks * 16);
+      vf[ks] = *(const bf16x8*)(vp + ks * 16);
+    }
+  }
+  const bool key_ok = mykey < len;
+  const float sl2 = p.scale * LOG2E;
+
+  // queries past the length carry exactly zero dO in this model (no loss there), so tiles stop at len
+  const int nqt = (blockIdx.x * 128 < len) ? ((len + 63) >> 6) : 0;
+  const int sr = tid >> 3, sc = tid & 7;
+  uint4 qr[2], dr[2];
+  float st_l = 0.f, st_d = 0.f;
+  const bf16_t* qbase = p.qkv + hd * 64;
+  const bf16_t* dobase = p.dctx + hd * 64;
+  const size_t statb = ((size_t)b * p.NH + hd) * S;
+  auto load_q = [&](int qt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int q = qt * 64 + sr + 32 * i; q = q < S ? q : S - 1;
+      qr[i] = *(const uint4*)(qbase + (tok0 + q) * ld + sc * 8);
+      dr[i] = *(const uint4*)(dobase + (tok0 + q) * p.lddctx + sc * 8);
+    }
+    if (tid < 64) {
+      int q = qt * 64 + tid; q = q < S ? q : S - 1;
+      st_l = p.lse[statb + q] * LOG2E;
+      st_d = p.delta[statb + q];
+    }
+  };
+  auto store_q = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = sr + 32 * i;
+      *(uint4*)&smem[st][0][row_off(r, sc)] = qr[i];
+      *(uint4*)&smem[st][1][tr_off(r, sc * 8)] = qr[i];
+      *(uint4*)&smem[st][2][row_off(r, sc)] = dr[i];
+      *(uint4*)&smem[st][3][tr_off(r, sc * 8)] = dr[i];
+    }
+    if (tid < 64) { sstat[st][0][tid] = st_l; sstat[st][1][tid] = st_d; }
+  };
+
+  f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+  if (nqt > 0) { load_q(0); store_q(0); }
+  __syncthreads();
+  for (int qt = 0; qt < nqt; ++qt) {
+    const int cur = qt & 1;
+    if (qt + 1 < nqt) load_q(qt + 1);
+    const bf16_t* sQ = smem[cur][0];
+    const bf16_t* sQt = smem[cur][1];
+    const bf16_t* sDO = smem[cur][2];
+    const bf16_t* sDOt = smem[cur][3];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, qb, ks, lane), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sDO, qb, ks, lane), vf[ks], dp, 0, 0, 0);
+      }
+      // s[r] = S[q][key]: key on the lane, q = qt*64 + qb*32 + (r&3) + 8(r>>2) + 4h
+      f32x16 ds;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int ql = qb * 32 + 8 * rg + 4 * h;
+        const float4 l4 = *(const float4*)&sstat[cur][0][ql];
+        const float4 d4 = *(const float4*)&sstat[cur][1][ql];
+        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = 4 * rg + j;
+          const bool ok = key_ok && (qt * 64 + ql + j < len);
+          const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * sl2 - lv[j]) : 0.f;
+          s[r] = pr;
+          ds[r] = pr * (dp[r] - dv[j]);
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pb = acc_frag(s, s2), dsb = acc_frag(ds, s2);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDOt, qb, s2, 0, lane), pb, dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDOt, qb, s2, 1, lane), pb, dv1, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQt, qb, s2, 0, lane), dsb, dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQt, qb, s2, 1, lane), dsb, dk1, 0, 0, 0);
+      }
+    }
+    if (qt + 1 < nqt) store_q(cur ^ 1);
+    __syncthreads();
+  }
+  bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
+  int rows_valid = S - key0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
+  if (rows_valid > 0) {
+    bf16_t* out = p.dqkv + (tok0 + key0) * p.lddqkv + hd * 64;
+    store_transposed(dk0, dk1, p.scale, patch, out + H, p.lddqkv, rows_valid, lane);
+    __builtin_amdgcn_wave_barrier();
+    store_transposed(dv0, dv1, 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane);
+  }
+}
+
+}  // namespace
+
+static int check_attn(const PlbAttn* p) {
+  if (p->H != p->NH * 64 || p->S < 1 || p->B < 1) return 1;
+  if (p->ldqkv % 8 || p->ldctx % 8) return 1;
+  return 0;
+}
+
+extern "C" int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream) {
+  if (check_attn(p)) return 1;
+  dim3 grid((p->S + 127) / 128, p->NH, p->B), block(256);
+  hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, stream, *p);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream) {
+  if (check_attn(p) || p->lddctx % 8 || p->lddqkv % 8) return 1;
+  dim3 grid((p->S + 127) / 128, p->NH, p->B), block(256);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, stream, *p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, stream, *p);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}

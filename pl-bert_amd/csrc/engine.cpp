@@ -1,0 +1,531 @@
+// C-ABI engine of the PL-BERT hot path (include/plbert.h): owns the workspace layout and the
+// launch sequence of one forward / loss+backward / AdamW step.  No device allocation, no host
+// synchronisation: everything is enqueued on the caller's HIP stream, so a caller may capture a
+// step into a hipGraph.
+//
+// Memory plan (sized for 288 GB HBM3E): every activation of all L applications of the shared layer
+// is stashed in bf16 as [L][Tp][width] (Tp = tokens rounded up to 128), and so is every gradient
+// that feeds a weight gradient.  Weight sharing then turns the 12 per-layer dW products of the
+// reference's autograd into ONE token-major GEMM per weight with reduction length L*Tp, which is
+// split over the grid into fp32 slabs and reduced in fixed order (deterministic, no atomics).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <new>
+
+#include "../../include/plbert.h"
+#include "plbert_kernels.h"
+
+static thread_local char g_err[512] = "";
+static int fail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return 1;
+}
+extern "C" const char* plb_last_error(void) { return g_err; }
+
+namespace {
+
+inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct Carve {  // bump allocator over the workspace, 256-B aligned regions
+  int64_t off = 0;
+  int64_t take(int64_t bytes) {
+    int64_t o = off;
+    off = rup(off + bytes, 256);
+    return o;
+  }
+};
+
+}  // namespace
+
+struct PlbEngine {
+  PlbConfig c;
+  int64_t poff[PLB_NPARAM], psize[PLB_NPARAM], ptotal, ptrain;
+  int E, H, I, L, NH, V, P, NP, NT;
+  int64_t Tcap;   // padded token capacity
+  int64_t NMcap;  // padded masked-row capacity
+  // workspace offsets (bytes)
+  int64_t o_wbf, o_wqkvT, o_wdT, o_w1T, o_w2T, o_wpT, o_winT;
+  int64_t o_e, o_x, o_qkv, o_ctx, o_pre1, o_a, o_u, o_g, o_pre2;
+  int64_t o_lse, o_delta, o_mean1, o_rstd1, o_mean2, o_rstd2;
+  int64_t o_dqkv, o_dpre1, o_du, o_dpre2;
+  int64_t o_dy0, o_dy1, o_da, o_dctx, o_de;
+  int64_t o_hm, o_logm, o_dlog, o_dhm, o_rows, o_tgt, o_w, o_lrows;
+  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_logfull;
+  int64_t slab_floats;
+  int64_t ws_bytes;
+  int ln_blocks, emb_blocks;
+  // bound buffers
+  float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
+  char* ws = nullptr;
+
+  template <typename T>
+  T* at(int64_t off) const { return reinterpret_cast<T*>(ws + off); }
+  bf16_t* wbf(int which) const { return at<bf16_t>(o_wbf) + poff[which]; }
+  float* par(int which) const { return params + poff[which]; }
+  float* grd(int which) const { return grads + poff[which]; }
+};
+
+static void layout_params(PlbEngine* e) {
+  const int64_t V = e->V, E = e->E, H = e->H, I = e->I, P = e->P, NP = e->NP, NT = e->NT;
+  int64_t sz[PLB_NPARAM];
+  sz[PLB_WORD_EMB] = V * E; sz[PLB_POS_EMB] = P * E; sz[PLB_TYPE_EMB] = (int64_t)e->c.type_vocab_size * E;
+  sz[PLB_EMB_LN_W] = E; sz[PLB_EMB_LN_B] = E;
+  sz[PLB_MAP_W] = H * E; sz[PLB_MAP_B] = H;
+  sz[PLB_LN2_W] = H; sz[PLB_LN2_B] = H;
+  sz[PLB_Q_W] = sz[PLB_K_W] = sz[PLB_V_W] = H * H;
+  sz[PLB_Q_B] = sz[PLB_K_B] = sz[PLB_V_B] = H;
+  sz[PLB_DENSE_W] = H * H; sz[PLB_DENSE_B] = H;
+  sz[PLB_LN1_W] = H; sz[PLB_LN1_B] = H;
+  sz[PLB_FFN_W] = I * H; sz[PLB_FFN_B] = I;
+  sz[PLB_FFNO_W] = H * I; sz[PLB_FFNO_B] = H;
+  sz[PLB_HEAD_W] = NP * H; sz[PLB_HEAD_B] = NP;
+  sz[PLB_POOL_W] = H * H; sz[PLB_POOL_B] = H;
+  sz[PLB_TOK_W] = NT * H; sz[PLB_TOK_B] = NT;
+  int64_t off = 0;
+  for (int i = 0; i < PLB_NPARAM; ++i) {
+    e->poff[i] = off;
+    e->psize[i] = sz[i];
+    off += sz[i];
+    if (i == PLB_HEAD_B) e->ptrain = off;
+  }
+  e->ptotal = off;
+}
+
+static int tn_splits(int64_t Mtot, int N, int K, int* rows_per_split) {
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int splits = 768 / tiles;
+  const int64_t maxs = Mtot / 64;
+  if (splits > maxs) splits = (int)maxs;
+  if (splits < 1) splits = 1;
+  int64_t rps = rup((Mtot + splits - 1) / splits, 64);
+  splits = (int)((Mtot + rps - 1) / rps);
+  *rows_per_split = (int)rps;
+  return splits;
+}
+
+extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
+  if (!cfg || !out) return fail("plb_create: null argument");
+  const PlbConfig& c = *cfg;
+  if (c.hidden_size != c.num_attention_heads * 64) return fail("plb_create: head_dim must be 64 (hidden %d, heads %d)", c.hidden_size, c.num_attention_heads);
+  if (c.embedding_size % 64 || c.embedding_size > 256) return fail("plb_create: embedding_size must be a multiple of 64, <= 256");
+  if (c.hidden_size % 128 || c.hidden_size > 1024) return fail("plb_create: hidden_size must be a multiple of 128, <= 1024");
+  if (c.intermediate_size % 128) return fail("plb_create: intermediate_size must be a multiple of 128");
+  if (c.num_phonemes < 4 || c.num_phonemes % 4 || c.num_phonemes > 256) return fail("plb_create: num_phonemes must be a multiple of 4 in [4,256]");
+  if (c.num_tokens < 0 || c.num_tokens % 4) return fail("plb_create: num_tokens must be a non-negative multiple of 4");
+  if (c.max_seq < 1 || c.max_seq > c.max_position_embeddings) return fail("plb_create: max_seq must be in [1, max_position_embeddings]");
+  if (c.max_batch < 1 || c.num_hidden_layers < 1 || c.vocab_size < 1 || c.type_vocab_size < 1) return fail("plb_create: bad sizes");
+  PlbEngine* e = new (std::nothrow) PlbEngine();
+  if (!e) return fail("plb_create: out of host memory");
+  e->c = c;
+  e->E = c.embedding_size; e->H = c.hidden_size; e->I = c.intermediate_size; e->L = c.num_hidden_layers;
+  e->NH = c.num_attention_heads; e->V = c.vocab_size; e->P = c.max_position_embeddings;
+  e->NP = c.num_phonemes; e->NT = c.num_tokens;
+  layout_params(e);
+  const int64_t E = e->E, H = e->H, I = e->I, L = e->L;
+  const int64_t T = (int64_t)c.max_batch * c.max_seq;
+  const int64_t Tp = rup(T, 128);
+  e->Tcap = Tp;
+  e->NMcap = Tp;
+  e->ln_blocks = 1024;
+  e->emb_blocks = 256;
+  Carve cv;
+  // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes
+  e->o_wbf = cv.take((e->ptotal + 256 * (H > I ? H : I)) * 2);
+  e->o_wqkvT = cv.take(rup(H, 128) * 3 * H * 2);
+  e->o_wdT = cv.take(rup(H, 128) * H * 2);
+  e->o_w1T = cv.take(rup(H, 128) * I * 2);
+  e->o_w2T = cv.take(rup(I, 128) * H * 2);
+  e->o_wpT = cv.take(rup(H, 128) * 256 * 2);
+  e->o_winT = cv.take(rup(E, 128) * H * 2);
+  // forward stash
+  e->o_e = cv.take(Tp * E * 2);
+  e->o_x = cv.take((L + 1) * Tp * H * 2);
+  e->o_qkv = cv.take(L * Tp * 3 * H * 2);
+  e->o_ctx = cv.take(L * Tp * H * 2);
+  e->o_pre1 = cv.take(L * Tp * H * 2);
+  e->o_a = cv.take(L * Tp * H * 2);
+  e->o_u = cv.take(L * Tp * I * 2);
+  e->o_g = cv.take(L * Tp * I * 2);
+  e->o_pre2 = cv.take(L * Tp * H * 2);
+  const int64_t stat = (int64_t)c.max_batch * e->NH * c.max_seq * 4;
+  e->o_lse = cv.take(L * stat);
+  e->o_delta = cv.take(stat);
+  e->o_mean1 = cv.take(L * Tp * 4); e->o_rstd1 = cv.take(L * Tp * 4);
+  e->o_mean2 = cv.take(L * Tp * 4); e->o_rstd2 = cv.take(L * Tp * 4);
+  // backward stash (operands of the batched dW GEMMs)
+  e->o_dqkv = cv.take(L * Tp * 3 * H * 2);
+  e->o_dpre1 = cv.take(L * Tp * H * 2);
+  e->o_du = cv.take(L * Tp * I * 2);
+  e->o_dpre2 = cv.take(L * Tp * H * 2);
+  e->o_dy0 = cv.take(Tp * H * 2); e->o_dy1 = cv.take(Tp * H * 2);
+  e->o_da = cv.take(Tp * H * 2); e->o_dctx = cv.take(Tp * H * 2);
+  e->o_de = cv.take(Tp * E * 2);
+  // loss rows
+  const int64_t NM = e->NMcap;
+  e->o_hm = cv.take(NM * H * 2);
+  e->o_logm = cv.take(NM * 256 * 4);
+  e->o_dlog = cv.take(NM * 256 * 2);
+  e->o_dhm = cv.take(NM * H * 2);
+  e->o_rows = cv.take(NM * 4); e->o_tgt = cv.take(NM * 4); e->o_w = cv.take(NM * 4); e->o_lrows = cv.take(NM * 4);
+  // reductions
+  int64_t slab = 0;
+  {
+    const int64_t Mtot = L * Tp;
+    const int shapes[6][2] = {{(int)(3 * H), (int)H}, {(int)H, (int)H}, {(int)I, (int)H}, {(int)H, (int)I}, {(int)H, (int)E}, {e->NP, (int)H}};
+    for (int i = 0; i < 6; ++i) {
+      int rps;
+      const int64_t mt = i < 4 ? Mtot : Tp;
+      const int s = tn_splits(mt, shapes[i][0], shapes[i][1], &rps);
+      const int64_t f = (int64_t)s * shapes[i][0] * shapes[i][1];
+      if (f > slab) slab = f;
+    }
+  }
+  e->slab_floats = slab;
+  e->o_slab = cv.take(slab * 4);
+  e->o_part1 = cv.take(L * e->ln_blocks * 2 * H * 4);
+  e->o_part2 = cv.take(L * e->ln_blocks * 2 * H * 4);
+  e->o_parte = cv.take((int64_t)e->emb_blocks * 2 * E * 4);
+  e->o_scratch = cv.take(64 * (3 * H > I ? 3 * H : I) * 4);
+  e->ws_bytes = cv.off;
+  *out = e;
+  return 0;
+}
+
+extern "C" void plb_destroy(PlbEngine* e) { delete e; }
+
+extern "C" int plb_param_layout(const PlbEngine* e, int64_t* offsets, int64_t* sizes, int64_t* total, int64_t* trainable) {
+  if (!e) return fail("plb_param_layout: null engine");
+  for (int i = 0; i < PLB_NPARAM; ++i) {
+    if (offsets) offsets[i] = e->poff[i];
+    if (sizes) sizes[i] = e->psize[i];
+  }
+  if (total) *total = e->ptotal;
+  if (trainable) *trainable = e->ptrain;
+  return 0;
+}
+
+extern "C" int64_t plb_workspace_bytes(const PlbEngine* e) { return e ? e->ws_bytes : -1; }
+
+extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_avg, float* exp_avg_sq, void* workspace,
+                        int64_t workspace_bytes) {
+  if (!e || !params || !workspace) return fail("plb_bind: null argument");
+  if (workspace_bytes < e->ws_bytes) return fail("plb_bind: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)e->ws_bytes);
+  if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) return fail("plb_bind: buffers must be 16-byte aligned");
+  if ((uintptr_t)workspace & 255) return fail("plb_bind: workspace must be 256-byte aligned");
+  e->params = params; e->grads = grads; e->m = exp_avg; e->v = exp_avg_sq;
+  e->ws = (char*)workspace;
+  return 0;
+}
+
+#define TRY(x)                                                                    \
+  do {                                                                            \
+    int rc_ = (x);                                                                \
+    if (rc_) return fail("%s failed (rc %d) at %s:%d", #x, rc_, __FILE__, __LINE__); \
+  } while (0)
+#define HIPTRY(x)                                                                                   \
+  do {                                                                                              \
+    hipError_t e_ = (x);                                                                            \
+    if (e_ != hipSuccess) return fail("%s: %s at %s:%d", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+static int sync_transposes(PlbEngine* e, hipStream_t s) {
+  const int H = e->H, I = e->I, E = e->E;
+  // fused QKV [3H,H] -> [H,3H]; the three tensors are adjacent in the flat buffer
+  TRY(plb_launch_transpose_cast(e->par(PLB_Q_W), 3 * H, H, e->at<bf16_t>(e->o_wqkvT), 3 * H, s));
+  TRY(plb_launch_transpose_cast(e->par(PLB_DENSE_W), H, H, e->at<bf16_t>(e->o_wdT), H, s));
+  TRY(plb_launch_transpose_cast(e->par(PLB_FFN_W), I, H, e->at<bf16_t>(e->o_w1T), I, s));
+  TRY(plb_launch_transpose_cast(e->par(PLB_FFNO_W), H, I, e->at<bf16_t>(e->o_w2T), H, s));
+  TRY(plb_launch_transpose_cast(e->par(PLB_HEAD_W), e->NP, H, e->at<bf16_t>(e->o_wpT), 256, s));
+  TRY(plb_launch_transpose_cast(e->par(PLB_MAP_W), H, E, e->at<bf16_t>(e->o_winT), H, s));
+  return 0;
+}
+
+extern "C" int plb_sync_weights(PlbEngine* e, void* stream) {
+  if (!e || !e->ws) return fail("plb_sync_weights: engine not bound");
+  hipStream_t s = (hipStream_t)stream;
+  TRY(plb_launch_cast_bf16(e->params, e->at<bf16_t>(e->o_wbf), (size_t)e->ptotal, s));
+  return sync_transposes(e, s);
+}
+
+static int check_shape(const PlbEngine* e, int B, int S, const char* who) {
+  if (!e || !e->ws) return fail("%s: engine not bound", who);
+  if (B < 1 || S < 1 || B > e->c.max_batch || S > e->c.max_seq || (int64_t)B * S > (int64_t)e->c.max_batch * e->c.max_seq)
+    return fail("%s: batch %d x seq %d exceeds the engine capacity %d x %d", who, B, S, e->c.max_batch, e->c.max_seq);
+  return 0;
+}
+
+// Embeddings + L applications of the shared layer. stash: keep every layer's activations (training)
+// or reuse the layer-0 slots (inference). Returns the final hidden buffer in *xout.
+static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths, int B, int S, bool stash, bf16_t** xout,
+                       hipStream_t s) {
+  const int E = e->E, H = e->H, I = e->I, L = e->L;
+  const int T = B * S;
+  const int64_t Tp = rup(T, 128);
+  PlbEmbed em;
+  memset(&em, 0, sizeof(em));
+  em.ids = ids; em.T = T; em.S = S; em.E = E; em.V = e->V;
+  em.word = e->par(PLB_WORD_EMB); em.pos = e->par(PLB_POS_EMB); em.type0 = e->par(PLB_TYPE_EMB);
+  em.gamma = e->par(PLB_EMB_LN_W); em.beta = e->par(PLB_EMB_LN_B); em.eps = e->c.layer_norm_eps;
+  em.out = e->at<bf16_t>(e->o_e); em.ldo = E;
+  TRY(plb_launch_embed_fwd(&em, s));
+
+  bf16_t* xall = e->at<bf16_t>(e->o_x);
+  PlbGemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.A = em.out; g.lda = E; g.B = e->wbf(PLB_MAP_W); g.ldb = E; g.M = (int)Tp; g.N = H; g.K = E; g.Mstore = (int)Tp;
+  g.bias = e->par(PLB_MAP_B); g.C = xall; g.ldc = H;
+  TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+
+  for (int l = 0; l < L; ++l) {
+    const int64_t sl = stash ? l : 0;
+    bf16_t* x = stash ? xall + (int64_t)l * Tp * H : xall + (int64_t)(l & 1) * Tp * H;
+    bf16_t* y = stash ? xall + (int64_t)(l + 1) * Tp * H : xall + (int64_t)((l + 1) & 1) * Tp * H;
+    bf16_t* qkv = e->at<bf16_t>(e->o_qkv) + sl * Tp * 3 * H;
+    bf16_t* ctx = e->at<bf16_t>(e->o_ctx) + sl * Tp * H;
+    bf16_t* pre1 = e->at<bf16_t>(e->o_pre1) + sl * Tp * H;
+    bf16_t* a = e->at<bf16_t>(e->o_a) + sl * Tp * H;
+    bf16_t* u = e->at<bf16_t>(e->o_u) + sl * Tp * I;
+    bf16_t* gl = e->at<bf16_t>(e->o_g) + sl * Tp * I;
+    bf16_t* pre2 = e->at<bf16_t>(e->o_pre2) + sl * Tp * H;
+    // fused QKV projection
+    memset(&g, 0, sizeof(g));
+    g.A = x; g.lda = H; g.B = e->wbf(PLB_Q_W); g.ldb = H; g.M = (int)Tp; g.N = 3 * H; g.K = H; g.Mstore = (int)Tp;
+    g.bias = e->par(PLB_Q_B); g.C = qkv; g.ldc = 3 * H;
+    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    PlbAttn at;
+    memset(&at, 0, sizeof(at));
+    at.qkv = qkv; at.ldqkv = 3 * H; at.lengths = lengths; at.B = B; at.S = S; at.NH = e->NH; at.H = H;
+    at.scale = 0.125f; at.ctx = ctx; at.ldctx = H;
+    at.lse = e->at<float>(e->o_lse) + sl * (int64_t)B * e->NH * S;
+    TRY(plb_launch_attn_fwd(&at, s));
+    // dense + residual, LayerNorm
+    memset(&g, 0, sizeof(g));
+    g.A = ctx; g.lda = H; g.B = e->wbf(PLB_DENSE_W); g.ldb = H; g.M = (int)Tp; g.N = H; g.K = H; g.Mstore = (int)Tp;
+    g.bias = e->par(PLB_DENSE_B); g.res = x; g.ldr = H; g.C = pre1; g.ldc = H;
+    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    PlbLayerNorm ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.beta = e->par(PLB_LN1_B); ln.eps = e->c.layer_norm_eps;
+    ln.y = a; ln.ldy = H; ln.T = T; ln.H = H;
+    ln.mean = e->at<float>(e->o_mean1) + sl * Tp; ln.rstd = e->at<float>(e->o_rstd1) + sl * Tp;
+    TRY(plb_launch_ln_fwd(&ln, s));
+    // FFN: u = a W1^T + b1, g = gelu_new(u); pre2 = g W2^T + b2 + a
+    memset(&g, 0, sizeof(g));
+    g.A = a; g.lda = H; g.B = e->wbf(PLB_FFN_W); g.ldb = H; g.M = (int)Tp; g.N = I; g.K = H; g.Mstore = (int)Tp;
+    g.bias = e->par(PLB_FFN_B); g.C = u; g.ldc = I; g.C2 = gl; g.ldc2 = I;
+    TRY(plb_launch_gemm_nt(&g, 1, 0, s));
+    memset(&g, 0, sizeof(g));
+    g.A = gl; g.lda = I; g.B = e->wbf(PLB_FFNO_W); g.ldb = I; g.M = (int)Tp; g.N = H; g.K = I; g.Mstore = (int)Tp;
+    g.bias = e->par(PLB_FFNO_B); g.res = a; g.ldr = H; g.C = pre2; g.ldc = H;
+    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    memset(&ln, 0, sizeof(ln));
+    ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.beta = e->par(PLB_LN2_B); ln.eps = e->c.layer_norm_eps;
+    ln.y = y; ln.ldy = H; ln.T = T; ln.H = H;
+    ln.mean = e->at<float>(e->o_mean2) + sl * Tp; ln.rstd = e->at<float>(e->o_rstd2) + sl * Tp;
+    TRY(plb_launch_ln_fwd(&ln, s));
+    *xout = y;
+  }
+  return 0;
+}
+
+extern "C" int plb_forward(PlbEngine* e, const int64_t* ids, const int32_t* lengths, int32_t B, int32_t S, float* hidden,
+                           float* phoneme_logits, float* token_logits, void* stream) {
+  if (check_shape(e, B, S, "plb_forward")) return 1;
+  if (!ids) return fail("plb_forward: ids is null");
+  if (token_logits && !e->NT) return fail("plb_forward: token_logits requested but num_tokens = 0");
+  hipStream_t s = (hipStream_t)stream;
+  const int H = e->H, T = B * S;
+  const int64_t Tp = rup(T, 128);
+  bf16_t* x = nullptr;
+  if (run_encoder(e, ids, lengths, B, S, false, &x, s)) return 1;
+  if (hidden) TRY(plb_launch_bf16_to_f32(x, H, hidden, H, T, H, s));
+  PlbGemmNT g;
+  if (phoneme_logits) {
+    memset(&g, 0, sizeof(g));
+    g.A = x; g.lda = H; g.B = e->wbf(PLB_HEAD_W); g.ldb = H; g.M = (int)Tp; g.N = e->NP; g.K = H; g.Mstore = T;
+    g.bias = e->par(PLB_HEAD_B); g.Cf = phoneme_logits; g.ldcf = e->NP;
+    TRY(plb_launch_gemm_nt(&g, 0, 1, s));
+  }
+  if (token_logits) {
+    memset(&g, 0, sizeof(g));
+    g.A = x; g.lda = H; g.B = e->wbf(PLB_TOK_W); g.ldb = H; g.M = (int)Tp; g.N = e->NT; g.K = H; g.Mstore = T;
+    g.bias = e->par(PLB_TOK_B); g.Cf = token_logits; g.ldcf = e->NT;
+    TRY(plb_launch_gemm_nt(&g, 0, 1, s));
+  }
+  return 0;
+}
+
+// dW[N,K] = A^T B over Mtot rows -> grads[which] (overwrite)
+static int weight_grad(PlbEngine* e, const bf16_t* A, int lda, int Ncols, const bf16_t* Bm, int ldb, int64_t Mtot, int N,
+                       int K, float* out, hipStream_t s) {
+  PlbGemmTN t;
+  memset(&t, 0, sizeof(t));
+  t.A = A; t.lda = lda; t.Ncols = Ncols; t.B = Bm; t.ldb = ldb; t.Mtot = (int)Mtot; t.N = N; t.K = K;
+  t.splits = tn_splits(Mtot, N, K, &t.rows_per_split);
+  if ((int64_t)t.splits * N * K > e->slab_floats) return fail("weight_grad: slab too small");
+  t.slab = e->at<float>(e->o_slab);
+  TRY(plb_launch_gemm_tn(&t, s));
+  TRY(plb_launch_reduce_slabs(t.slab, t.splits, (size_t)N * K, out, 0, s));
+  return 0;
+}
+
+extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int32_t* lengths,
+                                const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked, int32_t B,
+                                int32_t S, float* loss, void* stream) {
+  if (check_shape(e, B, S, "plb_loss_fwd_bwd")) return 1;
+  if (!e->grads) return fail("plb_loss_fwd_bwd: no gradient buffer bound");
+  if (!masked_ids || !labels || !idx_offsets || !loss) return fail("plb_loss_fwd_bwd: null argument");
+  if (n_masked < 0 || n_masked > e->NMcap) return fail("plb_loss_fwd_bwd: n_masked %d out of range", n_masked);
+  hipStream_t s = (hipStream_t)stream;
+  const int E = e->E, H = e->H, I = e->I, L = e->L, NP = e->NP;
+  const int T = B * S;
+  const int64_t Tp = rup(T, 128);
+  if (n_masked == 0) {  // train.py:129 — zero loss, nothing to back-propagate
+    HIPTRY(hipMemsetAsync(loss, 0, sizeof(float), s));
+    HIPTRY(hipMemsetAsync(e->grads, 0, (size_t)e->ptrain * 4, s));
+    return 0;
+  }
+  bf16_t* xL = nullptr;
+  if (run_encoder(e, masked_ids, lengths, B, S, true, &xL, s)) return 1;
+
+  // ---- masked rows: head GEMM, cross-entropy, head gradients ----------------------------------------
+  const int NM = (int)rup(n_masked, 128);
+  int32_t* rows = e->at<int32_t>(e->o_rows);
+  int32_t* tgt = e->at<int32_t>(e->o_tgt);
+  float* w = e->at<float>(e->o_w);
+  float* lrows = e->at<float>(e->o_lrows);
+  bf16_t* hm = e->at<bf16_t>(e->o_hm);
+  float* logm = e->at<float>(e->o_logm);
+  bf16_t* dlog = e->at<bf16_t>(e->o_dlog);
+  bf16_t* dhm = e->at<bf16_t>(e->o_dhm);
+  TRY(plb_launch_ce_prepare(idx_offsets, idx_flat, labels, B, S, rows, tgt, w, s));
+  TRY(plb_launch_gather_rows(xL, H, rows, n_masked, NM, H, hm, H, s));
+  PlbGemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.A = hm; g.lda = H; g.B = e->wbf(PLB_HEAD_W); g.ldb = H; g.M = NM; g.N = NP; g.K = H; g.Mstore = NM;
+  g.bias = e->par(PLB_HEAD_B); g.Cf = logm; g.ldcf = 256;
+  TRY(plb_launch_gemm_nt(&g, 0, 1, s));
+  TRY(plb_launch_ce_fwd_bwd(logm, 256, NP, tgt, w, n_masked, NM, lrows, dlog, 256, s));
+  TRY(plb_launch_sum_rows(lrows, n_masked, loss, s));
+  if (weight_grad(e, dlog, 256, 256, hm, H, NM, NP, H, e->grd(PLB_HEAD_W), s)) return 1;
+  float* scratch = e->at<float>(e->o_scratch);
+  TRY(plb_launch_colsum(dlog, 1, (size_t)NM, 256, 256, e->grd(PLB_HEAD_B), NP, 0, scratch, 8, s));
+  memset(&g, 0, sizeof(g));
+  g.A = dlog; g.lda = 256; g.B = e->at<bf16_t>(e->o_wpT); g.ldb = 256; g.M = NM; g.N = H; g.K = 256; g.Mstore = NM;
+  g.C = dhm; g.ldc = H;
+  TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+  bf16_t* dy = e->at<bf16_t>(e->o_dy0);
+  bf16_t* dy_other = e->at<bf16_t>(e->o_dy1);
+  HIPTRY(hipMemsetAsync(dy, 0, (size_t)Tp * H * 2, s));
+  TRY(plb_launch_scatter_rows(dhm, H, rows, n_masked, H, dy, H, s));
+
+  // ---- layers in reverse --------------------------------------------------------------------------------
+  bf16_t* da = e->at<bf16_t>(e->o_da);
+  bf16_t* dctx = e->at<bf16_t>(e->o_dctx);
+  for (int l = L - 1; l >= 0; --l) {
+    bf16_t* x_unused = nullptr; (void)x_unused;
+    bf16_t* qkv = e->at<bf16_t>(e->o_qkv) + (int64_t)l * Tp * 3 * H;
+    bf16_t* ctx = e->at<bf16_t>(e->o_ctx) + (int64_t)l * Tp * H;
+    bf16_t* pre1 = e->at<bf16_t>(e->o_pre1) + (int64_t)l * Tp * H;
+    bf16_t* u = e->at<bf16_t>(e->o_u) + (int64_t)l * Tp * I;
+    bf16_t* pre2 = e->at<bf16_t>(e->o_pre2) + (int64_t)l * Tp * H;
+    bf16_t* dqkv = e->at<bf16_t>(e->o_dqkv) + (int64_t)l * Tp * 3 * H;
+    bf16_t* dpre1 = e->at<bf16_t>(e->o_dpre1) + (int64_t)l * Tp * H;
+    bf16_t* du = e->at<bf16_t>(e->o_du) + (int64_t)l * Tp * I;
+    bf16_t* dpre2 = e->at<bf16_t>(e->o_dpre2) + (int64_t)l * Tp * H;
+    PlbLayerNorm ln;
+    memset(&ln, 0, sizeof(ln));
+    ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
+    ln.mean = e->at<float>(e->o_mean2) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd2) + (int64_t)l * Tp;
+    ln.dy = dy; ln.lddy = H; ln.dx = dpre2; ln.lddx = H;
+    ln.partials = e->at<float>(e->o_part2) + (int64_t)l * e->ln_blocks * 2 * H; ln.nblocks = e->ln_blocks;
+    TRY(plb_launch_ln_bwd(&ln, s));
+    // dU = (dpre2 · W2) ∘ gelu'(u)
+    memset(&g, 0, sizeof(g));
+    g.A = dpre2; g.lda = H; g.B = e->at<bf16_t>(e->o_w2T); g.ldb = H; g.M = (int)Tp; g.N = I; g.K = H; g.Mstore = (int)Tp;
+    g.aux = u; g.ldaux = I; g.C = du; g.ldc = I;
+    TRY(plb_launch_gemm_nt(&g, 2, 0, s));
+    // dA = dU · W1 + dpre2
+    memset(&g, 0, sizeof(g));
+    g.A = du; g.lda = I; g.B = e->at<bf16_t>(e->o_w1T); g.ldb = I; g.M = (int)Tp; g.N = H; g.K = I; g.Mstore = (int)Tp;
+    g.res = dpre2; g.ldr = H; g.C = da; g.ldc = H;
+    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    memset(&ln, 0, sizeof(ln));
+    ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
+    ln.mean = e->at<float>(e->o_mean1) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd1) + (int64_t)l * Tp;
+    ln.dy = da; ln.lddy = H; ln.dx = dpre1; ln.lddx = H;
+    ln.partials = e->at<float>(e->o_part1) + (int64_t)l * e->ln_blocks * 2 * H; ln.nblocks = e->ln_blocks;
+    TRY(plb_launch_ln_bwd(&ln, s));
+    // dCtx = dpre1 · Wd
+    memset(&g, 0, sizeof(g));
+    g.A = dpre1; g.lda = H; g.B = e->at<bf16_t>(e->o_wdT); g.ldb = H; g.M = (int)Tp; g.N = H; g.K = H; g.Mstore = (int)Tp;
+    g.C = dctx; g.ldc = H;
+    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    PlbAttn at;
+    memset(&at, 0, sizeof(at));
+    at.qkv = qkv; at.ldqkv = 3 * H; at.lengths = lengths; at.B = B; at.S = S; at.NH = e->NH; at.H = H; at.scale = 0.125f;
+    at.ctx = ctx; at.ldctx = H; at.lse = e->at<float>(e->o_lse) + (int64_t)l * B * e->NH * S;
+    at.dctx = dctx; at.lddctx = H; at.delta = e->at<float>(e->o_delta); at.dqkv = dqkv; at.lddqkv = 3 * H;
+    TRY(plb_launch_attn_bwd(&at, s));
+    if (Tp > T) HIPTRY(hipMemsetAsync(dqkv + (int64_t)T * 3 * H, 0, (size_t)(Tp - T) * 3 * H * 2, s));
+    // dX = dQKV · Wqkv + dpre1
+    memset(&g, 0, sizeof(g));
+    g.A = dqkv; g.lda = 3 * H; g.B = e->at<bf16_t>(e->o_wqkvT); g.ldb = 3 * H; g.M = (int)Tp; g.N = H; g.K = 3 * H;
+    g.Mstore = (int)Tp; g.res = dpre1; g.ldr = H; g.C = dy_other; g.ldc = H;
+    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    bf16_t* tmp = dy; dy = dy_other; dy_other = tmp;
+  }
+
+  // ---- embeddings ------------------------------------------------------------------------------------------
+  bf16_t* evec = e->at<bf16_t>(e->o_e);
+  bf16_t* de = e->at<bf16_t>(e->o_de);
+  memset(&g, 0, sizeof(g));
+  g.A = dy; g.lda = H; g.B = e->at<bf16_t>(e->o_winT); g.ldb = H; g.M = (int)Tp; g.N = E; g.K = H; g.Mstore = (int)Tp;
+  g.C = de; g.ldc = E;
+  TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+  if (weight_grad(e, dy, H, H, evec, E, Tp, H, E, e->grd(PLB_MAP_W), s)) return 1;
+  TRY(plb_launch_colsum(dy, 1, (size_t)Tp, H, H, e->grd(PLB_MAP_B), H, 0, scratch, 32, s));
+  HIPTRY(hipMemsetAsync(e->grd(PLB_WORD_EMB), 0, (size_t)(e->psize[PLB_WORD_EMB] + e->psize[PLB_POS_EMB] + e->psize[PLB_TYPE_EMB]) * 4, s));
+  PlbEmbed em;
+  memset(&em, 0, sizeof(em));
+  em.ids = masked_ids; em.T = T; em.S = S; em.E = E; em.V = e->V;
+  em.word = e->par(PLB_WORD_EMB); em.pos = e->par(PLB_POS_EMB); em.type0 = e->par(PLB_TYPE_EMB);
+  em.gamma = e->par(PLB_EMB_LN_W); em.beta = e->par(PLB_EMB_LN_B); em.eps = e->c.layer_norm_eps;
+  em.dout = de; em.lddo = E; em.dword = e->grd(PLB_WORD_EMB); em.dpos = e->grd(PLB_POS_EMB);
+  em.partials = e->at<float>(e->o_parte); em.nblocks = e->emb_blocks;
+  TRY(plb_launch_embed_bwd(&em, s));
+  TRY(plb_launch_colsum(em.partials, 0, (size_t)e->emb_blocks, 2 * E, 2 * E, e->grd(PLB_EMB_LN_W), 2 * E, 0, scratch, 1, s));
+  // token_type row 0 receives every token's gradient = the column sums of dpos
+  TRY(plb_launch_colsum(e->grd(PLB_POS_EMB), 0, (size_t)e->P, E, E, e->grd(PLB_TYPE_EMB), E, 0, scratch, 1, s));
+
+  // ---- shared-layer weight gradients: one token-major GEMM per weight over all L applications -----
+  const int64_t Mtot = (int64_t)L * Tp;
+  if (weight_grad(e, e->at<bf16_t>(e->o_dqkv), 3 * H, 3 * H, e->at<bf16_t>(e->o_x), H, Mtot, 3 * H, H, e->grd(PLB_Q_W), s)) return 1;
+  if (weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
+  if (weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
+  if (weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dqkv), 1, (size_t)Mtot, 3 * H, 3 * H, e->grd(PLB_Q_B), 3 * H, 0, scratch, 64, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre1), 1, (size_t)Mtot, H, H, e->grd(PLB_DENSE_B), H, 0, scratch, 64, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 64, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre2), 1, (size_t)Mtot, H, H, e->grd(PLB_FFNO_B), H, 0, scratch, 64, s));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, (size_t)L * e->ln_blocks, 2 * H, 2 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch, 16, s));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, (size_t)L * e->ln_blocks, 2 * H, 2 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch, 16, s));
+  return 0;
+}
+
+extern "C" int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              int32_t step, float grad_scale, void* stream) {
+  if (!e || !e->ws || !e->grads || !e->m || !e->v) return fail("plb_adamw_step: optimizer buffers not bound");
+  if (step < 1) return fail("plb_adamw_step: step counts from 1");
+  hipStream_t s = (hipStream_t)stream;
+  TRY(plb_launch_adamw(e->params, e->grads, e->m, e->v, e->at<bf16_t>(e->o_wbf), (size_t)e->ptrain, lr, beta1, beta2, eps,
+                       weight_decay, step, grad_scale, s));
+  return sync_transposes(e, s);
+}

@@ -1,0 +1,259 @@
+// bf16 MFMA GEMMs of the ALBERT step, gfx950.
+//
+//  gemm_nt : C[M,N] = A[M,K] · B[N,K]^T (+bias) (+residual) with fused epilogues
+//            forward projections (Y = X·W^T with W stored [out,in] as in the reference state-dict,
+//            modeling_albert.py:166-170,196,228-230,272; model.py:28) and the dX products of the
+//            backward pass (dX = dY·W computed as dY·(W^T)^T against the transposed weight copy).
+//  gemm_tn : dW[N,K] = A[Mtot,N]^T · B[Mtot,K]   (reduction over tokens, split over the grid; both
+//            operands are token-major, so fragments come from transposed LDS reads).
+//
+// Tile 128x128, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles, fp32
+// accumulate. Operands are staged global -> registers -> LDS (double buffered, one barrier per
+// k-tile); LDS images are XOR-swizzled / strip-rotated so ds_read_b128 / ds_read_b64_tr_b16 and
+// the ds_write_b128 staging stores are bank-conflict free.
+#include "common.h"
+#include "plbert_kernels.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+// ---- NT ------------------------------------------------------------------------------------------
+// LDS image of a [128 rows][64 k] bf16 tile: 128-B rows, 16-B chunk index XORed with (row>>1)&7.
+DEVI int nt_lds_off(int row, int chunk) { return row * BK + ((chunk ^ ((row >> 1) & 7)) << 3); }
+
+template <int ACT, bool OUTF32>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(PlbGemmNT p) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][BM * BK];  // [stage][A|B] 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int nbn = (p.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  const int logical = xcd_remap(blockIdx.x, nwg);
+  const int bm = logical / nbn, bn = logical % nbn;
+
+  const int lr = tid >> 3, lc = tid & 7;  // staging: 32 rows x 8 chunks per pass, 4 passes
+  const bf16_t* gA = p.A + (size_t)(bm * BM + lr) * p.lda + lc * 8;
+  const bf16_t* gB = p.B + (size_t)(bn * BN + lr) * p.ldb + lc * 8;
+  uint4 ra[4], rb[4];
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *(const uint4*)(gA + (size_t)(32 * i) * p.lda + kt * BK);
+      rb[i] = *(const uint4*)(gB + (size_t)(32 * i) * p.ldb + kt * BK);
+    }
+  };
+  auto store_tile = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int row = lr + 32 * i;
+      *(uint4*)&smem[st][0][nt_lds_off(row, lc)] = ra[i];
+      *(uint4*)&smem[st][1][nt_lds_off(row, lc)] = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int frow = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+    const bf16_t* sA = smem[cur][0];
+    const bf16_t* sB = smem[cur][1];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        af[i] = *(const bf16x8*)&sA[nt_lds_off(wr * 64 + i * 16 + frow, kk * 4 + fq)];
+        bfr[i] = *(const bf16x8*)&sB[nt_lds_off(wc * 64 + i * 16 + frow, kk * 4 + fq)];
+      }
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          // swapped operands: D[row = n][col = m] so each lane owns 4 consecutive n of one row m
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane holds C[m][n0..n0+3]
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+    const int m = bm * BM + wr * 64 + mi * 16 + frow;
+    if (m >= p.Mstore) continue;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int n0 = bn * BN + wc * 64 + ni * 16 + fq * 4;
+      if (n0 >= p.N) continue;
+      f32x4 v = acc[mi][ni];
+      if (p.bias) {
+        float4 b = *(const float4*)(p.bias + n0);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      if (p.res) {
+        uint2 r = *(const uint2*)(p.res + (size_t)m * p.ldr + n0);
+        v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
+      }
+      if (ACT == 2) {  // gelu backward: multiply by gelu_new'(u)
+        uint2 u = *(const uint2*)(p.aux + (size_t)m * p.ldaux + n0);
+        v[0] *= gelu_new_grad_f(bf_lo(u.x)); v[1] *= gelu_new_grad_f(bf_hi(u.x));
+        v[2] *= gelu_new_grad_f(bf_lo(u.y)); v[3] *= gelu_new_grad_f(bf_hi(u.y));
+      }
+      if (OUTF32) {
+        *(float4*)(p.Cf + (size_t)m * p.ldcf + n0) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+        *(uint2*)(p.C + (size_t)m * p.ldc + n0) = o;
+        if (ACT == 1) {  // gelu forward: C keeps the pre-activation u (rounded to bf16, as consumed by
+                         // the backward), C2 = gelu_new(u)
+          uint2 g;
+          g.x = pack_bf2(gelu_new_f(bf_lo(o.x)), gelu_new_f(bf_hi(o.x)));
+          g.y = pack_bf2(gelu_new_f(bf_lo(o.y)), gelu_new_f(bf_hi(o.y)));
+          *(uint2*)(p.C2 + (size_t)m * p.ldc2 + n0) = g;
+        }
+      }
+    }
+  }
+}
+
+// ---- TN ------------------------------------------------------------------------------------------
+// LDS image of a [64 t][128 cols] bf16 tile for transposed reads: 16-column strips, each strip a
+// run of 64 32-byte units (one per t) ordered so that t and t+8 are 4 units apart (bits 2,3 of t
+// swapped) and rotated by the strip index: a half-wave's ds_read_b64_tr_b16 (8 rows x 32 B) then
+// covers one contiguous 256-B window, and an 8-lane ds_write_b128 group covers 128 B.
+DEVI int tn_unit(int t) { return (t & 3) | (((t >> 3) & 1) << 2) | (((t >> 2) & 1) << 3) | (t & 48); }
+DEVI int tn_lds_off(int t, int col) {
+  int s = col >> 4;
+  return s * 1024 + (((tn_unit(t) + s) & 63) << 4) + (col & 15);
+}
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(PlbGemmTN p) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][64 * 128];  // [stage][A|B] 64 KiB
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int nbk = (p.K + 127) / 128;
+  const int bn = blockIdx.x / nbk, bk = blockIdx.x % nbk;
+  const int split = blockIdx.y;
+  const int t_begin = split * p.rows_per_split;
+  int t_end = t_begin + p.rows_per_split;
+  if (t_end > p.Mtot) t_end = p.Mtot;
+  const int nt = (t_end - t_begin) / 64;
+
+  const int lc = tid & 15, lr = tid >> 4;  // staging: 16 rows x 16 chunks per pass, 4 passes
+  const int colA = bn * 128 + lc * 8, colB = bk * 128 + lc * 8;
+  const bool okA = colA < p.Ncols, okB = colB < p.K;
+  uint4 ra[4], rb[4];
+  auto load_tile = [&](int it) {
+    const size_t t0 = (size_t)t_begin + (size_t)it * 64 + lr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = okA ? *(const uint4*)(p.A + (t0 + 16 * i) * p.lda + colA) : make_uint4(0, 0, 0, 0);
+      rb[i] = okB ? *(const uint4*)(p.B + (t0 + 16 * i) * p.ldb + colB) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto store_tile = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int off = tn_lds_off(lr + 16 * i, lc * 8);
+      *(uint4*)&smem[st][0][off] = ra[i];
+      *(uint4*)&smem[st][1][off] = rb[i];
+    }
+  };
+
+  f32x4 acc[4][4];  // [n tile][k tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, li = lane & 15, q = li >> 2, pp = li & 3;
+  if (nt > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int it = 0; it < nt; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < nt) load_tile(it + 1);
+    const bf16_t* sA = smem[cur][0];
+    const bf16_t* sB = smem[cur][1];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int t0 = ks * 32 + 8 * g + q;
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ca = wn * 64 + i * 16 + 4 * pp, cb = wk * 64 + i * 16 + 4 * pp;
+        s16x4 a0 = lds_read_tr16(&sA[tn_lds_off(t0, ca)]);
+        s16x4 a1 = lds_read_tr16(&sA[tn_lds_off(t0 + 4, ca)]);
+        s16x4 b0 = lds_read_tr16(&sB[tn_lds_off(t0, cb)]);
+        s16x4 b1 = lds_read_tr16(&sB[tn_lds_off(t0 + 4, cb)]);
+        af[i] = bf16x8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        bfr[i] = bf16x8{b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+      }
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int ki = 0; ki < 4; ++ki)
+          // D[row = k col][col = n]: lane owns 4 consecutive k of one output row n
+          acc[ni][ki] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ki], af[ni], acc[ni][ki], 0, 0, 0);
+    }
+    if (it + 1 < nt) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  float* out = p.slab + (size_t)split * p.N * p.K;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int n = bn * 128 + wn * 64 + ni * 16 + li;
+    if (n >= p.N) continue;
+#pragma unroll
+    for (int ki = 0; ki < 4; ++ki) {
+      const int k0 = bk * 128 + wk * 64 + ki * 16 + 4 * g;
+      if (k0 >= p.K) continue;
+      f32x4 v = acc[ni][ki];
+      *(float4*)(out + (size_t)n * p.K + k0) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {
+  if (p->M % BM || p->K % BK || p->N % 4 || p->M <= 0 || p->N <= 0 || p->K <= 0) return 1;
+  const int nbn = (p->N + BN - 1) / BN;
+  dim3 grid((p->M / BM) * nbn), block(256);
+  if (out_f32) {
+    if (act != 0) return 1;
+    hipLaunchKernelGGL((gemm_nt_kernel<0, true>), grid, block, 0, stream, *p);
+  } else if (act == 0) {
+    hipLaunchKernelGGL((gemm_nt_kernel<0, false>), grid, block, 0, stream, *p);
+  } else if (act == 1) {
+    hipLaunchKernelGGL((gemm_nt_kernel<1, false>), grid, block, 0, stream, *p);
+  } else if (act == 2) {
+    hipLaunchKernelGGL((gemm_nt_kernel<2, false>), grid, block, 0, stream, *p);
+  } else {
+    return 1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+extern "C" int plb_launch_gemm_tn(const PlbGemmTN* p, hipStream_t stream) {
+  if (p->Mtot % 64 || p->rows_per_split % 64 || p->K % 4 || p->N <= 0 || p->splits <= 0) return 1;
+  if ((long)p->splits * p->rows_per_split < p->Mtot) return 1;
+  dim3 grid(((p->N + 127) / 128) * ((p->K + 127) / 128), p->splits), block(256);
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, stream, *p);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}

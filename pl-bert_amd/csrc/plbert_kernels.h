@@ -1,0 +1,114 @@
+// Internal launch interface between the HIP kernel files and the C-ABI engine (engine.cpp).
+// Not installed; the public boundary is include/plbert.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+extern "C" {
+
+// C[M,N] = A[M,K]·B[N,K]^T (+bias)(+res); M%128==0, K%64==0, N%4==0, B readable for ceil128(N) rows.
+typedef struct {
+  const bf16_t* A; int lda;
+  const bf16_t* B; int ldb;
+  int M, N, K;
+  int Mstore;                   // rows >= Mstore are computed but not stored
+  const float* bias;            // [N] or null
+  const bf16_t* res; int ldr;   // residual [M,N] or null
+  const bf16_t* aux; int ldaux; // act==2: pre-activation u
+  bf16_t* C; int ldc;           // bf16 out (act==1: pre-activation u)
+  bf16_t* C2; int ldc2;         // act==1: gelu_new(u)
+  float* Cf; int ldcf;          // out_f32
+} PlbGemmNT;
+int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream);
+
+// slab[split][N][K] = A[rows,N]^T · B[rows,K] over the split's rows; Mtot%64==0, rows_per_split%64==0,
+// Ncols (readable columns of A) %8==0, K%8==0.
+typedef struct {
+  const bf16_t* A; int lda; int Ncols;
+  const bf16_t* B; int ldb;
+  int Mtot, N, K;
+  int rows_per_split, splits;
+  float* slab;
+} PlbGemmTN;
+int plb_launch_gemm_tn(const PlbGemmTN* p, hipStream_t stream);
+
+// out[n] (+)= sum over splits of slab[s][n]   (n = count of floats)
+int plb_launch_reduce_slabs(const float* slab, int splits, size_t n, float* out, int accumulate, hipStream_t stream);
+
+// Embeddings: e = LN_E(word[ids] + type[0] + pos[t % S]) -> bf16 [T,E]
+typedef struct {
+  const int64_t* ids; int T, S, E, V;
+  const float *word, *pos, *type0, *gamma, *beta;
+  float eps;
+  bf16_t* out; int ldo;
+  // backward
+  const bf16_t* dout; int lddo;
+  float *dword, *dpos;          // fp32 [V,E], [P,E] accumulated with atomics (zeroed by the caller)
+  float* partials;              // [nblocks][2E] : dgamma | dbeta partial sums
+  int nblocks;
+} PlbEmbed;
+int plb_launch_embed_fwd(const PlbEmbed* p, hipStream_t stream);
+int plb_launch_embed_bwd(const PlbEmbed* p, hipStream_t stream);  // grid = p->nblocks
+
+// LayerNorm over rows of width H (H%4==0, H<=1024): y = LN(x)*g+b ; stats saved for the backward
+typedef struct {
+  const bf16_t* x; int ldx;
+  const float *gamma, *beta; float eps;
+  bf16_t* y; int ldy;
+  float *mean, *rstd;           // [T]
+  int T, H;
+  int Tzero;                    // backward: rows T..Tzero-1 of dx are written as zeros
+  // backward: dx = LN'(dy); partials[nblocks][2H] = dgamma | dbeta
+  const bf16_t* dy; int lddy;
+  bf16_t* dx; int lddx;
+  float* partials; int nblocks;
+} PlbLayerNorm;
+int plb_launch_ln_fwd(const PlbLayerNorm* p, hipStream_t stream);
+int plb_launch_ln_bwd(const PlbLayerNorm* p, hipStream_t stream);
+
+// out[N] (+)= column sums of X[R,N]; is_bf16 selects the element type. scratch: [nsplit][N] floats.
+// Only the first Nout (<= N) sums are written to out.
+int plb_launch_colsum(const void* X, int is_bf16, size_t R, int N, int ld, float* out, int Nout, int accumulate,
+                      float* scratch, int nsplit, hipStream_t stream);
+
+// Attention over the fused qkv buffer [T,3H] (Q | K | V, head h at columns h*64..h*64+63), head_dim 64.
+typedef struct {
+  const bf16_t* qkv; int ldqkv;
+  const int32_t* lengths;       // [B] valid keys per sample, or null (= S)
+  int B, S, NH, H;
+  float scale;                  // head_dim^-0.5
+  bf16_t* ctx; int ldctx;       // [T,H]
+  float* lse;                   // [B,NH,S]
+  // backward
+  const bf16_t* dctx; int lddctx;
+  float* delta;                 // [B,NH,S]
+  bf16_t* dqkv; int lddqkv;     // [T,3H]
+} PlbAttn;
+int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream);
+int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream);  // dq (+delta) then dk,dv
+
+// Loss rows: row r of the gathered matrix is token rows[r]
+int plb_launch_gather_rows(const bf16_t* src, int lds_, const int32_t* rows, int n, int npad, int H, bf16_t* dst,
+                           int ldd, hipStream_t stream);
+int plb_launch_scatter_rows(const bf16_t* src, int lds_, const int32_t* rows, int n, int H, bf16_t* dst, int ldd,
+                            hipStream_t stream);
+// From the CSR index lists: rows[j] = b*S + idx, tgt[j] = labels[b,idx], w[j] = 1/(n_b * count)
+int plb_launch_ce_prepare(const int32_t* offsets, const int32_t* flat, const int64_t* labels, int B, int S,
+                          int32_t* rows, int32_t* tgt, float* w, hipStream_t stream);
+// per row: loss_rows[j] = w*(lse - z[tgt]); dlogits[j,:] = w*(softmax - onehot) (bf16, zero padded to ldd cols)
+int plb_launch_ce_fwd_bwd(const float* logits, int ldl, int V, const int32_t* tgt, const float* w, int n, int npad,
+                          float* loss_rows, bf16_t* dlogits, int ldd, hipStream_t stream);
+// loss[0] = sum(loss_rows[0..n))  (single block, deterministic order)
+int plb_launch_sum_rows(const float* x, int n, float* out, hipStream_t stream);
+
+// AdamW (torch.optim.AdamW semantics) over a flat range; also refreshes the bf16 compute copy.
+int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, float lr, float beta1,
+                     float beta2, float eps, float wd, int step, float grad_scale, hipStream_t stream);
+int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream);
+// dst[c, r] = bf16(src[r, c]) for r<R, c<C ; dst has ldd >= R columns (zero fill is the caller's job)
+int plb_launch_transpose_cast(const float* src, int R, int C, bf16_t* dst, int ldd, hipStream_t stream);
+int plb_launch_bf16_to_f32(const bf16_t* src, int lds_, float* dst, int ldd, int R, int C, hipStream_t stream);
+
+}  // extern "C"

@@ -1,0 +1,526 @@
+// HBM-bound row kernels of the PL-BERT step, gfx950: embedding gather + LayerNorm (fwd/bwd),
+// LayerNorm(H) fwd/bwd, column sums (bias / LayerNorm-affine gradients), masked-row gather/scatter,
+// masked cross-entropy fwd+bwd, slab reduction, AdamW, casts and transposes.
+// One wave per row, 8-byte (4 x bf16) accesses, wave-shuffle reductions, fp32 statistics
+// (layer_norm_eps = 1e-12 is below bf16 resolution).
+#include "common.h"
+#include "plbert_kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------------- embeddings (A4 / A11)
+// AlbertEmbeddings.forward (modeling_albert.py:67-106): LN_E(word[id] + type[0] + pos[s]); E <= 256.
+template <bool BWD>
+__global__ __launch_bounds__(256) void embed_kernel(PlbEmbed p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int E = p.E;
+  const int c = lane * 4;  // this lane's 4 columns
+  const bool act = c < E;
+  float4 g4 = make_float4(0, 0, 0, 0), b4 = g4, ty = g4;
+  if (act) {
+    g4 = *(const float4*)(p.gamma + c);
+    b4 = *(const float4*)(p.beta + c);
+    ty = *(const float4*)(p.type0 + c);
+  }
+  float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+  const float invE = 1.0f / (float)E;
+  for (int t = blockIdx.x * 4 + wave; t < p.T; t += gridDim.x * 4) {
+    long long id = p.ids[t];
+    if (id < 0 || id >= p.V) id = 0;  // host validates; never index out of the table
+    const int s = t % p.S;
+    float x[4] = {0, 0, 0, 0};
+    if (act) {
+      float4 w = *(const float4*)(p.word + (size_t)id * E + c);
+      float4 ps = *(const float4*)(p.pos + (size_t)s * E + c);
+      x[0] = w.x + ty.x + ps.x; x[1] = w.y + ty.y + ps.y; x[2] = w.z + ty.z + ps.z; x[3] = w.w + ty.w + ps.w;
+    }
+    const float mean = wave_sum(x[0] + x[1] + x[2] + x[3]) * invE;
+    float d[4], vs = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { d[j] = act ? x[j] - mean : 0.f; vs += d[j] * d[j]; }
+    const float rstd = rsqrtf(wave_sum(vs) * invE + p.eps);
+    if (!BWD) {
+      if (act) {
+        uint2 o;
+        o.x = pack_bf2(d[0] * rstd * g4.x + b4.x, d[1] * rstd * g4.y + b4.y);
+        o.y = pack_bf2(d[2] * rstd * g4.z + b4.z, d[3] * rstd * g4.w + b4.w);
+        *(uint2*)(p.out + (size_t)t * p.ldo + c) = o;
+      }
+    } else {
+      float dy[4] = {0, 0, 0, 0}, xh[4], dxh[4], s1 = 0.f, s2 = 0.f;
+      if (act) {
+        uint2 u = *(const uint2*)(p.dout + (size_t)t * p.lddo + c);
+        dy[0] = bf_lo(u.x); dy[1] = bf_hi(u.x); dy[2] = bf_lo(u.y); dy[3] = bf_hi(u.y);
+      }
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[j] = d[j] * rstd;
+        dxh[j] = dy[j] * gg[j];
+        s1 += dxh[j]; s2 += dxh[j] * xh[j];
+        dg[j] += dy[j] * xh[j]; db[j] += dy[j];
+      }
+      s1 = wave_sum(s1) * invE; s2 = wave_sum(s2) * invE;
+      if (act) {
+        float dx[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dx[j] = rstd * (dxh[j] - s1 - xh[j] * s2);
+        float* dp = p.dpos + (size_t)s * E + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(dp + j, dx[j]);
+        if (id != 0) {  // nn.Embedding(padding_idx=0): the pad row gets no gradient
+          float* dw = p.dword + (size_t)id * E + c;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) atomicAdd(dw + j, dx[j]);
+        }
+      }
+    }
+  }
+  if (BWD) {
+    __shared__ float red[4][2][256];
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { red[wave][0][c + j] = dg[j]; red[wave][1][c + j] = db[j]; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * E; i += 256) {
+      const int which = i / E, col = i % E;
+      p.partials[(size_t)blockIdx.x * 2 * E + i] =
+          red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- LayerNorm(H) (A7/A8)
+// nn.LayerNorm over the last dim, biased variance, eps inside the sqrt. NCH = ceil(H/256).
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(PlbLayerNorm p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = p.H;
+  const float invH = 1.0f / (float)H;
+  for (int t = blockIdx.x * 4 + wave; t < p.T; t += gridDim.x * 4) {
+    float x[NCH][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        uint2 u = *(const uint2*)(p.x + (size_t)t * p.ldx + c);
+        x[i][0] = bf_lo(u.x); x[i][1] = bf_hi(u.x); x[i][2] = bf_lo(u.y); x[i][3] = bf_hi(u.y);
+      } else {
+        x[i][0] = x[i][1] = x[i][2] = x[i][3] = 0.f;
+      }
+      s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
+    }
+    const float mean = wave_sum(s) * invH;
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + 64 * i) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x[i][j] = (c < H) ? x[i][j] - mean : 0.f; vs += x[i][j] * x[i][j]; }
+    }
+    const float rstd = rsqrtf(wave_sum(vs) * invH + p.eps);
+    if (lane == 0 && p.mean) { p.mean[t] = mean; p.rstd[t] = rstd; }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        float4 g = *(const float4*)(p.gamma + c), b = *(const float4*)(p.beta + c);
+        uint2 o;
+        o.x = pack_bf2(x[i][0] * rstd * g.x + b.x, x[i][1] * rstd * g.y + b.y);
+        o.y = pack_bf2(x[i][2] * rstd * g.z + b.z, x[i][3] * rstd * g.w + b.w);
+        *(uint2*)(p.y + (size_t)t * p.ldy + c) = o;
+      }
+    }
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
+  __shared__ float red[4][2][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int H = p.H;
+  const float invH = 1.0f / (float)H;
+  float dg[NCH][4], db[NCH][4], gm[NCH][4];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    float4 g = (c < H) ? *(const float4*)(p.gamma + c) : make_float4(0, 0, 0, 0);
+    gm[i][0] = g.x; gm[i][1] = g.y; gm[i][2] = g.z; gm[i][3] = g.w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
+  }
+  for (int t = blockIdx.x * 4 + wave; t < p.T; t += gridDim.x * 4) {
+    const float mean = p.mean[t], rstd = p.rstd[t];
+    float xh[NCH][4], dxh[NCH][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      float xv[4] = {0, 0, 0, 0}, dyv[4] = {0, 0, 0, 0};
+      if (c < H) {
+        uint2 u = *(const uint2*)(p.x + (size_t)t * p.ldx + c);
+        uint2 d = *(const uint2*)(p.dy + (size_t)t * p.lddy + c);
+        xv[0] = bf_lo(u.x); xv[1] = bf_hi(u.x); xv[2] = bf_lo(u.y); xv[3] = bf_hi(u.y);
+        dyv[0] = bf_lo(d.x); dyv[1] = bf_hi(d.x); dyv[2] = bf_lo(d.y); dyv[3] = bf_hi(d.y);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xh[i][j] = (c < H) ? (xv[j] - mean) * rstd : 0.f;
+        dxh[i][j] = dyv[j] * gm[i][j];
+        s1 += dxh[i][j]; s2 += dxh[i][j] * xh[i][j];
+        dg[i][j] += dyv[j] * xh[i][j]; db[i][j] += dyv[j];
+      }
+    }
+    s1 = wave_sum(s1) * invH; s2 = wave_sum(s2) * invH;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) {
+        uint2 o;
+        o.x = pack_bf2(rstd * (dxh[i][0] - s1 - xh[i][0] * s2), rstd * (dxh[i][1] - s1 - xh[i][1] * s2));
+        o.y = pack_bf2(rstd * (dxh[i][2] - s1 - xh[i][2] * s2), rstd * (dxh[i][3] - s1 - xh[i][3] * s2));
+        *(uint2*)(p.dx + (size_t)t * p.lddx + c) = o;
+      }
+    }
+  }
+  // padding rows of the token dimension: keep them zero so they add nothing to the batched dW GEMMs
+  for (int t = p.T + blockIdx.x * 4 + wave; t < p.Tzero; t += gridDim.x * 4) {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = (lane + 64 * i) * 4;
+      if (c < H) *(uint2*)(p.dx + (size_t)t * p.lddx + c) = make_uint2(0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    if (c < H) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { red[wave][0][c + j] = dg[i][j]; red[wave][1][c + j] = db[i][j]; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * H; i += 256) {
+    const int which = i / H, col = i % H;
+    p.partials[(size_t)blockIdx.x * 2 * H + i] =
+        red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+  }
+}
+
+// ------------------------------------------------------------------------------------ column sums
+// scratch[split][n] = sum of rows of the split; a block covers 256 columns x its row range:
+// 32 lanes x 8 columns per row, 8 rows in flight per block (4 waves x 2 half-waves).
+template <bool BF16>
+__global__ __launch_bounds__(256) void colsum_kernel(const void* X, size_t R, int N, int ld, float* scratch, int nsplit) {
+  __shared__ float red[8][256];
+  const int tid = threadIdx.x;
+  const int rsub = tid >> 5, cl = tid & 31;
+  const int c = blockIdx.x * 256 + cl * 8;
+  const size_t rows_per = (R + nsplit - 1) / nsplit;
+  const size_t r0 = (size_t)blockIdx.y * rows_per;
+  size_t r1 = r0 + rows_per; if (r1 > R) r1 = R;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < N) {
+    for (size_t r = r0 + rsub; r < r1; r += 8) {
+      if (BF16) {
+        uint4 u = *(const uint4*)((const bf16_t*)X + r * ld + c);
+        acc[0] += bf_lo(u.x); acc[1] += bf_hi(u.x); acc[2] += bf_lo(u.y); acc[3] += bf_hi(u.y);
+        acc[4] += bf_lo(u.z); acc[5] += bf_hi(u.z); acc[6] += bf_lo(u.w); acc[7] += bf_hi(u.w);
+      } else {
+        const float* px = (const float*)X + r * ld + c;
+        float4 a = *(const float4*)px, b = *(const float4*)(px + 4);
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rsub][cl * 8 + j] = acc[j];
+  __syncthreads();
+  const int col = blockIdx.x * 256 + tid;
+  if (col < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][tid];
+    scratch[(size_t)blockIdx.y * N + col] = s;
+  }
+}
+
+__global__ void reduce_slabs_kernel(const float* slab, int splits, size_t n, float* out, int accumulate) {
+  const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  if (i + 4 <= n) {
+    float4 s = accumulate ? *(const float4*)(out + i) : make_float4(0, 0, 0, 0);
+    for (int k = 0; k < splits; ++k) {
+      float4 v = *(const float4*)(slab + (size_t)k * n + i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *(float4*)(out + i) = s;
+  } else {
+    for (size_t j = i; j < n; ++j) {
+      float s = accumulate ? out[j] : 0.f;
+      for (int k = 0; k < splits; ++k) s += slab[(size_t)k * n + j];
+      out[j] = s;
+    }
+  }
+}
+
+__global__ void reduce_cols_kernel(const float* scratch, int nsplit, int N, int Nout, float* out, int accumulate) {
+  const int j0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  for (int j = j0; j < j0 + 4 && j < Nout; ++j) {
+    float s = accumulate ? out[j] : 0.f;
+    for (int k = 0; k < nsplit; ++k) s += scratch[(size_t)k * N + j];
+    out[j] = s;
+  }
+}
+
+// -------------------------------------------------------------------- masked rows + cross entropy
+__global__ void gather_rows_kernel(const bf16_t* src, int lds_, const int32_t* rows, int n, int npad, int H,
+                                   bf16_t* dst, int ldd) {
+  const int r = blockIdx.x;
+  const int chunks = H / 8;
+  const bool live = r < n;
+  const size_t srow = live ? (size_t)rows[r] : 0;
+  for (int c = threadIdx.x; c < chunks; c += blockDim.x) {
+    uint4 v = live ? *(const uint4*)(src + srow * lds_ + c * 8) : make_uint4(0, 0, 0, 0);
+    *(uint4*)(dst + (size_t)r * ldd + c * 8) = v;
+  }
+}
+__global__ void scatter_rows_kernel(const bf16_t* src, int lds_, const int32_t* rows, int n, int H, bf16_t* dst,
+                                    int ldd) {
+  const int r = blockIdx.x;
+  if (r >= n) return;
+  const size_t drow = (size_t)rows[r];
+  for (int c = threadIdx.x; c < H / 8; c += blockDim.x)
+    *(uint4*)(dst + drow * ldd + c * 8) = *(const uint4*)(src + (size_t)r * lds_ + c * 8);
+}
+// calculate_phoneme_loss (train.py:107-131): per-sample mean over its masked indices, then mean over
+// the samples that have any. One thread per sample.
+__global__ void ce_prepare_kernel(const int32_t* offsets, const int32_t* flat, const int64_t* labels, int B, int S,
+                                  int32_t* rows, int32_t* tgt, float* w) {
+  __shared__ int count;
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int b = 0; b < B; ++b) c += offsets[b + 1] > offsets[b];
+    count = c;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < B; b += blockDim.x) {
+    const int j0 = offsets[b], j1 = offsets[b + 1];
+    const float wb = (j1 > j0) ? 1.0f / ((float)(j1 - j0) * (float)count) : 0.f;
+    for (int j = j0; j < j1; ++j) {
+      const int idx = flat[j];
+      rows[j] = b * S + idx;
+      tgt[j] = (int32_t)labels[(size_t)b * S + idx];
+      w[j] = wb;
+    }
+  }
+}
+// nn.CrossEntropyLoss on one row per wave: V <= 256 classes, 4 per lane.
+__global__ __launch_bounds__(256) void ce_kernel(const float* logits, int ldl, int V, const int32_t* tgt, const float* w,
+                                                 int n, int npad, float* loss_rows, bf16_t* dlogits, int ldd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  if (r >= npad) return;
+  const int c = lane * 4;
+  if (r >= n) {  // padding rows: zero gradient
+    if (c < ldd) *(uint2*)(dlogits + (size_t)r * ldd + c) = make_uint2(0, 0);
+    return;
+  }
+  float z[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) z[j] = (c + j < V) ? logits[(size_t)r * ldl + c + j] : -INFINITY;
+  const float mx = wave_max(fmaxf(fmaxf(z[0], z[1]), fmaxf(z[2], z[3])));
+  float e[4], s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { e[j] = (c + j < V) ? __expf(z[j] - mx) : 0.f; s += e[j]; }
+  s = wave_sum(s);
+  const int t = tgt[r];
+  const float wr = w[r];
+  float zt = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) zt += (c + j == t) ? z[j] : 0.f;
+  zt = wave_sum(zt);
+  if (lane == 0) loss_rows[r] = wr * (mx + __logf(s) - zt);
+  const float inv = wr / s;
+  if (c < ldd) {
+    float g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[j] = (c + j < V) ? e[j] * inv - ((c + j == t) ? wr : 0.f) : 0.f;
+    uint2 o; o.x = pack_bf2(g[0], g[1]); o.y = pack_bf2(g[2], g[3]);
+    *(uint2*)(dlogits + (size_t)r * ldd + c) = o;
+  }
+}
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* x, int n, float* out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+// -------------------------------------------------------------------------------- optimizer (A12)
+// torch.optim.AdamW single-tensor semantics: p *= 1 - lr*wd; m,v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* pb, size_t n,
+                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                    float rsqrt_bc2, float gscale) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;  // n is a multiple of 4 (checked by the launcher)
+  float4 P = *(const float4*)(p + i), G = *(const float4*)(g + i), M = *(const float4*)(m + i), V = *(const float4*)(v + i);
+  float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
+  const float step = lr / bc1, decay = 1.0f - lr * wd;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float gj = gg[j] * gscale;
+    pp[j] *= decay;
+    mm[j] = b1 * mm[j] + (1.0f - b1) * gj;
+    vv[j] = b2 * vv[j] + (1.0f - b2) * gj * gj;
+    const float denom = sqrtf(vv[j]) * rsqrt_bc2 + eps;
+    pp[j] -= step * (mm[j] / denom);
+  }
+  *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
+  *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+  *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  if (pb) { uint2 o; o.x = pack_bf2(pp[0], pp[1]); o.y = pack_bf2(pp[2], pp[3]); *(uint2*)(pb + i) = o; }
+}
+__global__ void cast_bf16_kernel(const float* src, bf16_t* dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = f2bf(src[i]);
+}
+__global__ void transpose_cast_kernel(const float* src, int R, int C, bf16_t* dst, int ldd) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < C && r < R) dst[(size_t)c * ldd + r] = f2bf(tile[tx][k]);
+  }
+}
+__global__ void bf16_to_f32_kernel(const bf16_t* src, int lds_, float* dst, int ldd, int R, int C) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * C) return;
+  const size_t r = i / C, c = i % C;
+  dst[r * ldd + c] = bf2f(src[r * lds_ + c]);
+}
+
+}  // namespace
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : 2)
+
+extern "C" int plb_launch_embed_fwd(const PlbEmbed* p, hipStream_t stream) {
+  if (p->E % 4 || p->E > 256 || p->T <= 0) return 1;
+  int blocks = (p->T + 3) / 4; if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL((embed_kernel<false>), dim3(blocks), dim3(256), 0, stream, *p);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_embed_bwd(const PlbEmbed* p, hipStream_t stream) {
+  if (p->E % 4 || p->E > 256 || p->T <= 0 || p->nblocks <= 0) return 1;
+  hipLaunchKernelGGL((embed_kernel<true>), dim3(p->nblocks), dim3(256), 0, stream, *p);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_ln_fwd(const PlbLayerNorm* p, hipStream_t stream) {
+  if (p->H % 4 || p->H > 1024 || p->T <= 0) return 1;
+  int blocks = (p->T + 3) / 4; if (blocks > 4096) blocks = 4096;
+  const int nch = (p->H + 255) / 256;
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((ln_fwd_kernel<1>), dim3(blocks), dim3(256), 0, stream, *p); break;
+    case 2: hipLaunchKernelGGL((ln_fwd_kernel<2>), dim3(blocks), dim3(256), 0, stream, *p); break;
+    case 3: hipLaunchKernelGGL((ln_fwd_kernel<3>), dim3(blocks), dim3(256), 0, stream, *p); break;
+    default: hipLaunchKernelGGL((ln_fwd_kernel<4>), dim3(blocks), dim3(256), 0, stream, *p); break;
+  }
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_ln_bwd(const PlbLayerNorm* p, hipStream_t stream) {
+  if (p->H % 4 || p->H > 1024 || p->T <= 0 || p->nblocks <= 0) return 1;
+  const int nch = (p->H + 255) / 256;
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(p->nblocks), dim3(256), 0, stream, *p); break;
+    case 2: hipLaunchKernelGGL((ln_bwd_kernel<2>), dim3(p->nblocks), dim3(256), 0, stream, *p); break;
+    case 3: hipLaunchKernelGGL((ln_bwd_kernel<3>), dim3(p->nblocks), dim3(256), 0, stream, *p); break;
+    default: hipLaunchKernelGGL((ln_bwd_kernel<4>), dim3(p->nblocks), dim3(256), 0, stream, *p); break;
+  }
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_reduce_slabs(const float* slab, int splits, size_t n, float* out, int accumulate,
+                                       hipStream_t stream) {
+  if (!n) return 0;
+  const size_t threads = (n + 3) / 4;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, slab, splits, n,
+                     out, accumulate);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_colsum(const void* X, int is_bf16, size_t R, int N, int ld, float* out, int Nout,
+                                 int accumulate, float* scratch, int nsplit, hipStream_t stream) {
+  if (N % 8 || ld % 8 || nsplit <= 0 || Nout > N) return 1;
+  dim3 grid((N + 255) / 256, nsplit);
+  if (is_bf16) hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, stream, X, R, N, ld, scratch, nsplit);
+  else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, stream, X, R, N, ld, scratch, nsplit);
+  if (hipGetLastError() != hipSuccess) return 2;
+  const size_t threads = ((size_t)Nout + 3) / 4;
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, scratch, nsplit,
+                     N, Nout, out, accumulate);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_gather_rows(const bf16_t* src, int lds_, const int32_t* rows, int n, int npad, int H,
+                                      bf16_t* dst, int ldd, hipStream_t stream) {
+  if (H % 8 || npad <= 0) return 1;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(npad), dim3(128), 0, stream, src, lds_, rows, n, npad, H, dst, ldd);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_scatter_rows(const bf16_t* src, int lds_, const int32_t* rows, int n, int H, bf16_t* dst,
+                                       int ldd, hipStream_t stream) {
+  if (H % 8) return 1;
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(128), 0, stream, src, lds_, rows, n, H, dst, ldd);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_ce_prepare(const int32_t* offsets, const int32_t* flat, const int64_t* labels, int B, int S,
+                                     int32_t* rows, int32_t* tgt, float* w, hipStream_t stream) {
+  hipLaunchKernelGGL(ce_prepare_kernel, dim3(1), dim3(256), 0, stream, offsets, flat, labels, B, S, rows, tgt, w);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_ce_fwd_bwd(const float* logits, int ldl, int V, const int32_t* tgt, const float* w, int n,
+                                     int npad, float* loss_rows, bf16_t* dlogits, int ldd, hipStream_t stream) {
+  if (V > 256 || ldd > 256 || ldd % 4 || npad <= 0) return 1;
+  hipLaunchKernelGGL(ce_kernel, dim3((npad + 3) / 4), dim3(256), 0, stream, logits, ldl, V, tgt, w, n, npad, loss_rows,
+                     dlogits, ldd);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_sum_rows(const float* x, int n, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, stream, x, n, out);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, float lr,
+                                float beta1, float beta2, float eps, float wd, int step, float grad_scale,
+                                hipStream_t stream) {
+  if (n % 4 || step < 1) return 1;
+  if (!n) return 0;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, p_bf16, n, lr,
+                     beta1, beta2, eps, wd, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_transpose_cast(const float* src, int R, int C, bf16_t* dst, int ldd, hipStream_t stream) {
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, src, R, C, dst, ldd);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_bf16_to_f32(const bf16_t* src, int lds_, float* dst, int ldd, int R, int C, hipStream_t stream) {
+  const size_t n = (size_t)R * C;
+  if (!n) return 0;
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, lds_, dst, ldd, R, C);
+  return LAUNCH_OK();
+}

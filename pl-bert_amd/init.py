@@ -44,10 +44,11 @@ def param_shapes(cfg, num_phonemes, num_tokens=0):
     s[LAYER + "ffn.bias"] = (I,)
     s[LAYER + "ffn_output.weight"] = (H, I)
     s[LAYER + "ffn_output.bias"] = (H,)
-    s[ENC + "pooler.weight"] = (H, H)
-    s[ENC + "pooler.bias"] = (H,)
     s["phoneme_predictor.weight"] = (num_phonemes, H)
     s["phoneme_predictor.bias"] = (num_phonemes,)
+    # parameters below never receive a gradient in the reference's step (train.py:383-390)
+    s[ENC + "pooler.weight"] = (H, H)
+    s[ENC + "pooler.bias"] = (H,)
     if num_tokens:
         s["token_predictor.weight"] = (num_tokens, H)
         s["token_predictor.bias"] = (num_tokens,)

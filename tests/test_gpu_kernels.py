@@ -1,0 +1,141 @@
+"""Kernel-level parity (-m gpu): each HIP kernel, launched through the C ABI, against a plain
+PyTorch fp32 reference of the same op on the same bf16-rounded inputs."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from plbert_amd import _lib
+from gpu_util import attn_args, bf16_round, gemm_nt, gemm_tn, rel_l2, stream, torch_attention
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def gelu_new(x):
+    return 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def randbf(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (384, 768, 2048), (128, 188, 768)])
+def test_gemm_nt_bias_residual(M, N, K):
+    A, Bw = randbf(M, K, seed=1), randbf((N + 127) // 128 * 128, K, scale=0.05, seed=2)
+    bias = torch.randn(N, device=DEV)
+    res = randbf(M, N, seed=3)
+    out, _ = gemm_nt(A, Bw, N, bias=bias, res=res)
+    ref = A.float() @ Bw[:N].float().T + bias + res.float()
+    assert (out.float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-3
+    assert rel_l2(out.float(), ref) < 4e-3  # bf16 output rounding
+    outf, _ = gemm_nt(A, Bw, N, bias=bias, out_f32=True, Mstore=M - 5)
+    reff = A.float() @ Bw[:N].float().T + bias
+    assert rel_l2(outf[: M - 5], reff[: M - 5]) < 1e-5
+    assert (outf[M - 5:] == 0).all()  # rows past Mstore untouched
+
+
+def test_gemm_nt_gelu_epilogues():
+    M, N, K = 256, 256, 128
+    A, Bw = randbf(M, K, seed=4), randbf(N, K, scale=0.2, seed=5)
+    bias = torch.randn(N, device=DEV) * 0.1
+    u, g = gemm_nt(A, Bw, N, bias=bias, act=1)
+    uref = A.float() @ Bw.float().T + bias
+    assert rel_l2(u.float(), uref) < 4e-3
+    assert (g.float() - gelu_new(u.float())).abs().max() < 2e-2 * max(1.0, float(u.float().abs().max()))
+    assert rel_l2(g.float(), gelu_new(u.float())) < 5e-3
+    # backward epilogue: (A·B^T) * gelu'(aux) + nothing
+    aux = randbf(M, N, scale=1.5, seed=6)
+    du, _ = gemm_nt(A, Bw, N, aux=aux, act=2)
+    x = aux.float().clone().requires_grad_(True)
+    gelu_new(x).sum().backward()
+    ref = (A.float() @ Bw.float().T) * x.grad
+    assert rel_l2(du.float(), ref) < 5e-3
+
+
+@pytest.mark.parametrize("Mtot,Ncols,N,K,splits,rps", [(256, 128, 128, 128, 1, 256), (1024, 256, 188, 192, 3, 384),
+                                                       (2048, 384, 384, 64, 4, 512), (640, 2304, 2304, 768, 2, 320)])
+def test_gemm_tn(Mtot, Ncols, N, K, splits, rps):
+    A, Bm = randbf(Mtot, Ncols, seed=7), randbf(Mtot, K, seed=8)
+    out = gemm_tn(A, Bm, N, splits, rps)
+    ref = A.float().T[:N] @ Bm.float()
+    assert rel_l2(out, ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,S,NH,lens", [(3, 40, 2, [40, 33, 7]), (2, 512, 3, [512, 300]), (2, 130, 2, None),
+                                         (1, 64, 1, [1])])
+def test_attention_fwd_bwd(B, S, NH, lens):
+    L = _lib.lib()
+    H = NH * 64
+    qkv = randbf(B * S, 3 * H, scale=1.0, seed=9)
+    lengths = torch.tensor(lens, dtype=torch.int32, device=DEV) if lens else None
+    p, ctx, lse = attn_args(qkv, lengths, B, S, NH)
+    assert L.plb_launch_attn_fwd(C.byref(p), stream()) == 0
+    torch.cuda.synchronize()
+    rctx, rlse, grad = torch_attention(qkv, lengths, B, S, NH)
+    assert rel_l2(ctx.float(), rctx) < 6e-3
+    assert (lse - rlse).abs().max() < 2e-3
+    # backward: dctx zero on padded queries (as in the model), random elsewhere
+    dctx = randbf(B * S, H, seed=10)
+    if lens:
+        qmask = (torch.arange(S, device=DEV)[None, :] < lengths[:, None]).reshape(B * S, 1)
+        dctx = dctx * qmask.to(dctx.dtype)
+    delta = torch.zeros((B, NH, S), dtype=torch.float32, device=DEV)
+    dqkv = torch.full((B * S, 3 * H), 7.0, dtype=torch.bfloat16, device=DEV)
+    p.dctx, p.lddctx, p.delta, p.dqkv, p.lddqkv = dctx.data_ptr(), H, delta.data_ptr(), dqkv.data_ptr(), 3 * H
+    assert L.plb_launch_attn_bwd(C.byref(p), stream()) == 0
+    torch.cuda.synchronize()
+    ref = grad(dctx)
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        assert rel_l2(dqkv[:, sl].float(), ref[:, sl]) < 1.5e-2, name
+    if lens:  # padded keys get exactly zero dK, dV
+        kpad = ~(torch.arange(S, device=DEV)[None, :] < lengths[:, None]).reshape(B * S)
+        assert (dqkv[kpad][:, H:] == 0).all()
+
+
+@pytest.mark.parametrize("T,H", [(37, 128), (300, 768), (64, 1024)])
+def test_layernorm_fwd_bwd(T, H):
+    L = _lib.lib()
+    x = randbf(T + 3, H, scale=2.0, seed=11)
+    gam = (1 + 0.1 * torch.randn(H, device=DEV)).contiguous()
+    bet = (0.1 * torch.randn(H, device=DEV)).contiguous()
+    y = torch.zeros((T + 3, H), dtype=torch.bfloat16, device=DEV)
+    mean = torch.zeros(T + 3, device=DEV)
+    rstd = torch.zeros(T + 3, device=DEV)
+    p = _lib.PlbLayerNorm()
+    p.x, p.ldx, p.gamma, p.beta, p.eps = x.data_ptr(), H, gam.data_ptr(), bet.data_ptr(), 1e-12
+    p.y, p.ldy, p.mean, p.rstd, p.T, p.H, p.Tzero = y.data_ptr(), H, mean.data_ptr(), rstd.data_ptr(), T, H, T + 3
+    assert L.plb_launch_ln_fwd(C.byref(p), stream()) == 0
+    xr = x[:T].float().clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (H,), gam, bet, eps=1e-12)
+    torch.cuda.synchronize()
+    assert rel_l2(y[:T].float(), yr.detach()) < 4e-3
+    dy = randbf(T + 3, H, seed=12)
+    dx = torch.full((T + 3, H), 3.0, dtype=torch.bfloat16, device=DEV)
+    nb = 64
+    part = torch.zeros((nb, 2 * H), device=DEV)
+    p.dy, p.lddy, p.dx, p.lddx, p.partials, p.nblocks = dy.data_ptr(), H, dx.data_ptr(), H, part.data_ptr(), nb
+    assert L.plb_launch_ln_bwd(C.byref(p), stream()) == 0
+    torch.cuda.synchronize()
+    gw = torch.nn.Parameter(gam.clone())
+    gb = torch.nn.Parameter(bet.clone())
+    xr2 = x[:T].float().clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr2, (H,), gw, gb, eps=1e-12).backward(dy[:T].float())
+    assert rel_l2(dx[:T].float(), xr2.grad) < 5e-3
+    assert (dx[T:] == 0).all()
+    assert rel_l2(part.sum(0)[:H], gw.grad) < 1e-4
+    assert rel_l2(part.sum(0)[H:], gb.grad) < 1e-4
+
+
+def test_colsum():
+    L = _lib.lib()
+    R, N = 1000, 776
+    x = randbf(R, 784, seed=13)
+    out = torch.zeros(N - 4, device=DEV)
+    scratch = torch.zeros(16 * N, device=DEV)
+    assert L.plb_launch_colsum(x.data_ptr(), 1, R, N, 784, out.data_ptr(), N - 4, 0, scratch.data_ptr(), 16, stream()) == 0
+    torch.cuda.synchronize()
+    assert rel_l2(out, x[:, : N - 4].float().sum(0)) < 1e-5
