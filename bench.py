@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""PL-BERT pre-training hot path on MI355X: phoneme-tokens/s of the full training step.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = masked-phoneme forward -> per-sample masked cross-entropy -> backward -> gradient
+all-reduce (N > 1, RCCL) -> AdamW, on one synthetic fixed-length batch per rank that is resident in
+HBM before the timed region (BASELINE.json configs[1]: ALBERT hidden 768 / 12 shared layers / FFN
+2048, seq 512, batch 32 per GPU; weak scaling).  Prints ONE JSON line on rank 0.
+
+roofline: the dominant kernel class of the step, algorithmic FLOPs per launch / average launch
+duration, from per-launch HIP events recorded on the launch stream during a re-run of the same K
+steps (the clean timed region carries no events).  cpu_baseline: the numpy oracle's training step
+(oracle/albert_np.py, kind "port") on the host cores, rank 0 at N=1 only, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+FLOP_PER_TOKEN_STEP = 454_440_960  # 3 x 151,480,320 forward, config A
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
+    ap.add_argument("--seq", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(budget_s):
+    """The oracle's full training step (fwd + loss + bwd + AdamW, fp32 numpy) on a bounded sample of
+    the same workload: batches of 2 x 512 tokens, repeated until the budget is used."""
+    from threadpoolctl import threadpool_limits
+    from oracle import albert_np as onp
+    import plbert_amd
+
+    threads = min(os.cpu_count() or 1, 16)
+    pcfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                                   max_position_embeddings=512, num_hidden_layers=12)
+    sd = plbert_amd.deterministic_state_dict(pcfg, 188, seed=0)
+    ocfg = onp.Config()
+    B, S = 2, 512
+    labels, masked, lengths, idx = plbert_amd.synthetic_batch(B, S, seed=1234)
+    opt = onp.AdamW(lr=7e-5)
+    with threadpool_limits(limits=threads):
+        onp.train_step(ocfg, sd, opt, masked, labels, lengths, idx)  # warm-up (BLAS init, page faults)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            onp.train_step(ocfg, sd, opt, masked, labels, lengths, idx)
+            n += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
+        dt = time.perf_counter() - t0
+    return {"value": round(n * B * S / dt, 1), "unit": "tokens/s", "cores": threads, "kind": "port",
+            "sample": f"{n} full training steps (fwd+loss+bwd+AdamW, fp32 numpy oracle) of {B}x{S} tokens, "
+                      f"768/12 model, {dt:.1f} s wall"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import plbert_amd
+    from plbert_amd import _lib
+    from plbert_amd.train import PLBertTrainer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+
+    cfg = plbert_amd.AlbertConfig(vocab_size=len(plbert_amd.symbols), hidden_size=768, num_attention_heads=12,
+                                  intermediate_size=2048, max_position_embeddings=512, num_hidden_layers=12)
+    B, S = args.batch, args.seq
+    trainer = PLBertTrainer(cfg, num_phonemes=len(plbert_amd.symbols), max_batch=B, max_seq=S, lr=7e-5,
+                            device=f"cuda:{local_rank}", seed=0)
+    labels, masked, lengths, idx = plbert_amd.synthetic_batch(B, S, seed=1234 + rank)
+    batch = trainer.stage_batch(labels, masked, lengths, idx)  # resident in HBM before timing
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.step(batch)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(batch)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(loss.item())
+
+    roofline = None
+    if not args.no_roofline:
+        _lib.profile_enable(True)
+        for _ in range(args.steps):
+            trainer.step(batch)
+        torch.cuda.synchronize()
+        prof = _lib.profile_read()
+        _lib.profile_enable(False)
+        if rank == 0 and prof:
+            total_ms = sum(v["ms"] for v in prof.values())
+            name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+            per_launch_flop = dom["flops"] / dom["launches"]
+            avg_ms = dom["ms"] / dom["launches"]
+            ach = per_launch_flop / (avg_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                        "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": dom["launches"] // args.steps,
+                        "share_of_kernel_time": round(dom["ms"] / total_ms, 3),
+                        "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in
+                                               sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+                        "step_mfma_frac": round(FLOP_PER_TOKEN_STEP * B * S / (total_ms / args.steps * 1e-3) / 1e12
+                                                / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_seconds)
+
+    if rank == 0:
+        tokens = world * B * S * args.steps
+        out = {
+            "metric": "phoneme-tokens/sec", "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"PL-BERT masked-phoneme training step (fwd+loss+bwd+allreduce+AdamW), ALBERT "
+                                   f"hidden 768 / 12 shared layers / FFN 2048 / 12 heads, seq_len {S}, batch {B} per GPU",
+                       "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
+            "step_loss": round(loss_val, 5),
+            "step_mfma_frac_wall": round(FLOP_PER_TOKEN_STEP * B * S / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -123,6 +123,15 @@ int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* lab
 int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float grad_scale, void* stream);
 
+/* Measurement aid (no reference counterpart; the reference has no profiling): when
+ * enabled, every kernel launch is bracketed by two HIP events on its stream. plb_profile_read waits
+ * for them and returns, per kernel class, total milliseconds, launch count and the algorithmic
+ * flops / bytes of those launches (arrays of plb_profile_num_classes() entries), then clears. */
+void plb_profile_enable(int on);
+int plb_profile_num_classes(void);
+const char* plb_profile_class_name(int cls);
+int plb_profile_read(double* ms, int64_t* launches, double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

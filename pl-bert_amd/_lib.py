@@ -52,6 +52,7 @@ PLB_NPARAM = len(PLB_PARAM_NAMES)
 PUBLIC_SYMBOLS = [
     "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
     "plb_sync_weights", "plb_forward", "plb_loss_fwd_bwd", "plb_adamw_step",
+    "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
 ]
 
 
@@ -142,6 +143,14 @@ def lib():
     L.plb_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.plb_adamw_step.restype = C.c_int
     L.plb_adamw_step.argtypes = [vp, f32, f32, f32, f32, f32, i32, f32, vp]
+    L.plb_profile_enable.restype = None
+    L.plb_profile_enable.argtypes = [C.c_int]
+    L.plb_profile_num_classes.restype = C.c_int
+    L.plb_profile_num_classes.argtypes = []
+    L.plb_profile_class_name.restype = C.c_char_p
+    L.plb_profile_class_name.argtypes = [C.c_int]
+    L.plb_profile_read.restype = C.c_int
+    L.plb_profile_read.argtypes = [C.POINTER(C.c_double), i64p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     # internal launchers (kernel-level tests)
     L.plb_launch_gemm_nt.restype = C.c_int
     L.plb_launch_gemm_nt.argtypes = [C.POINTER(PlbGemmNT), C.c_int, C.c_int, vp]
@@ -161,6 +170,21 @@ def lib():
     L.plb_launch_colsum.argtypes = [vp, C.c_int, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]
     _lib = L
     return L
+
+
+def profile_enable(on):
+    lib().plb_profile_enable(int(bool(on)))
+
+
+def profile_read():
+    """{class name: dict(ms, launches, flops, bytes)} for the launches recorded since the last read."""
+    L = lib()
+    n = L.plb_profile_num_classes()
+    ms, fl, by = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)()
+    cnt = (C.c_int64 * n)()
+    check(L.plb_profile_read(ms, cnt, fl, by), "plb_profile_read")
+    return {L.plb_profile_class_name(i).decode(): dict(ms=ms[i], launches=int(cnt[i]), flops=fl[i], bytes=by[i])
+            for i in range(n) if cnt[i]}
 
 
 def check(rc, what):

@@ -421,14 +421,26 @@ static int check_attn(const PlbAttn* p) {
 extern "C" int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream) {
   if (check_attn(p)) return 1;
   dim3 grid((p->S + 127) / 128, p->NH, p->B), block(256);
+  const double unit = (double)p->B * p->NH * (double)p->S * p->S * 64.0;
+  const double io = 2.0 * p->B * p->S * (double)p->H;
+  const int tok = plb_prof_begin(PLB_K_ATTN_FWD, stream, 4.0 * unit, 4.0 * io);
   hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, stream, *p);
+  plb_prof_end(tok, stream);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
 extern "C" int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream) {
   if (check_attn(p) || p->lddctx % 8 || p->lddqkv % 8) return 1;
   dim3 grid((p->S + 127) / 128, p->NH, p->B), block(256);
+  // algorithmic work of the backward = 4 products (dP, dQ, dV, dK); the S recomputation in each
+  // kernel and the second dP are not credited
+  const double unit = (double)p->B * p->NH * (double)p->S * p->S * 64.0;
+  const double io = 2.0 * p->B * p->S * (double)p->H;
+  int tok = plb_prof_begin(PLB_K_ATTN_BWD_DQ, stream, 4.0 * unit, 6.0 * io);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, block, 0, stream, *p);
+  plb_prof_end(tok, stream);
+  tok = plb_prof_begin(PLB_K_ATTN_BWD_DKV, stream, 4.0 * unit, 6.0 * io);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, stream, *p);
+  plb_prof_end(tok, stream);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }

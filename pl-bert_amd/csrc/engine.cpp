@@ -29,6 +29,54 @@ static int fail(const char* fmt, ...) {
 }
 extern "C" const char* plb_last_error(void) { return g_err; }
 
+// ---- per-launch HIP-event profiler ----------------------------------------------------------------------
+// When enabled every launcher brackets its kernel with two events on the launch stream; reading
+// synchronises on them and sums elapsed time, launches and algorithmic flops/bytes per kernel class.
+#include <vector>
+namespace {
+struct ProfRec { int cls; hipEvent_t a, b; double flops, bytes; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::vector<hipEvent_t> g_pool;
+const char* const kClassNames[PLB_K_NCLASS] = {
+    "gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32", "gemm_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv",
+    "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "reduce_slabs", "gather_scatter_rows", "cross_entropy",
+    "adamw", "cast_transpose"};
+hipEvent_t prof_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+extern "C" int plb_prof_begin(int cls, hipStream_t s, double flops, double bytes) {
+  if (!g_prof_on) return -1;
+  ProfRec r{cls, prof_event(), prof_event(), flops, bytes};
+  (void)hipEventRecord(r.a, s);
+  g_prof.push_back(r);
+  return (int)g_prof.size() - 1;
+}
+extern "C" void plb_prof_end(int tok, hipStream_t s) {
+  if (tok >= 0 && tok < (int)g_prof.size()) (void)hipEventRecord(g_prof[tok].b, s);
+}
+extern "C" void plb_profile_enable(int on) { g_prof_on = on != 0; }
+extern "C" int plb_profile_num_classes(void) { return PLB_K_NCLASS; }
+extern "C" const char* plb_profile_class_name(int cls) { return (cls >= 0 && cls < PLB_K_NCLASS) ? kClassNames[cls] : ""; }
+// Waits for every recorded launch, fills per-class totals (arrays of plb_profile_num_classes()
+// entries: milliseconds, launches, flops, bytes) and clears the record.
+extern "C" int plb_profile_read(double* ms, int64_t* launches, double* flops, double* bytes) {
+  for (int i = 0; i < PLB_K_NCLASS; ++i) { ms[i] = 0; launches[i] = 0; flops[i] = 0; bytes[i] = 0; }
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return fail("plb_profile_read: event sync failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return fail("plb_profile_read: elapsed failed");
+    ms[r.cls] += t; launches[r.cls] += 1; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes;
+    g_pool.push_back(r.a); g_pool.push_back(r.b);
+  }
+  g_prof.clear();
+  return 0;
+}
+
 namespace {
 
 inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

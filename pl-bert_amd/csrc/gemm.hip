@@ -235,6 +235,12 @@ extern "C" int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipS
   if (p->M % BM || p->K % BK || p->N % 4 || p->M <= 0 || p->N <= 0 || p->K <= 0) return 1;
   const int nbn = (p->N + BN - 1) / BN;
   dim3 grid((p->M / BM) * nbn), block(256);
+  const int cls = out_f32 ? PLB_K_GEMM_NT_F32 : act == 1 ? PLB_K_GEMM_NT_GELU : act == 2 ? PLB_K_GEMM_NT_GELUBWD : PLB_K_GEMM_NT;
+  const double mnk = (double)p->M * p->N * p->K;
+  const int tok = plb_prof_begin(cls, stream, 2.0 * mnk,
+                                 2.0 * ((double)p->M * p->K + (double)p->N * p->K) +
+                                     (double)p->M * p->N * (out_f32 ? 4 : act == 1 ? 4 : 2) +
+                                     (p->res ? 2.0 * p->M * p->N : 0.0) + (act == 2 ? 2.0 * p->M * p->N : 0.0));
   if (out_f32) {
     if (act != 0) return 1;
     hipLaunchKernelGGL((gemm_nt_kernel<0, true>), grid, block, 0, stream, *p);
@@ -247,6 +253,7 @@ extern "C" int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipS
   } else {
     return 1;
   }
+  plb_prof_end(tok, stream);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
@@ -254,6 +261,9 @@ extern "C" int plb_launch_gemm_tn(const PlbGemmTN* p, hipStream_t stream) {
   if (p->Mtot % 64 || p->rows_per_split % 64 || p->K % 4 || p->N <= 0 || p->splits <= 0) return 1;
   if ((long)p->splits * p->rows_per_split < p->Mtot) return 1;
   dim3 grid(((p->N + 127) / 128) * ((p->K + 127) / 128), p->splits), block(256);
+  const int tok = plb_prof_begin(PLB_K_GEMM_TN, stream, 2.0 * p->Mtot * (double)p->N * p->K,
+                                 2.0 * p->Mtot * ((double)p->N + p->K) + 4.0 * p->splits * (double)p->N * p->K);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, stream, *p);
+  plb_prof_end(tok, stream);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }

@@ -415,21 +415,31 @@ __global__ void bf16_to_f32_kernel(const bf16_t* src, int lds_, float* dst, int 
 }  // namespace
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : 2)
+namespace {
+struct ProfScope {  // brackets every launch made while it is alive with one pair of HIP events
+  int tok; hipStream_t s;
+  ProfScope(int cls, hipStream_t st, double flops, double bytes) : tok(plb_prof_begin(cls, st, flops, bytes)), s(st) {}
+  ~ProfScope() { plb_prof_end(tok, s); }
+};
+}  // namespace
 
 extern "C" int plb_launch_embed_fwd(const PlbEmbed* p, hipStream_t stream) {
   if (p->E % 4 || p->E > 256 || p->T <= 0) return 1;
   int blocks = (p->T + 3) / 4; if (blocks > 2048) blocks = 2048;
+  ProfScope ps(PLB_K_EMBED_FWD, stream, 0, (double)p->T * (8 + 2.0 * p->E));
   hipLaunchKernelGGL((embed_kernel<false>), dim3(blocks), dim3(256), 0, stream, *p);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_embed_bwd(const PlbEmbed* p, hipStream_t stream) {
   if (p->E % 4 || p->E > 256 || p->T <= 0 || p->nblocks <= 0) return 1;
+  ProfScope ps(PLB_K_EMBED_BWD, stream, 0, (double)p->T * (8 + 2.0 * p->E + 8.0 * p->E));
   hipLaunchKernelGGL((embed_kernel<true>), dim3(p->nblocks), dim3(256), 0, stream, *p);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_ln_fwd(const PlbLayerNorm* p, hipStream_t stream) {
   if (p->H % 4 || p->H > 1024 || p->T <= 0) return 1;
   int blocks = (p->T + 3) / 4; if (blocks > 4096) blocks = 4096;
+  ProfScope ps(PLB_K_LN_FWD, stream, 0, (double)p->T * (4.0 * p->H + 8));
   const int nch = (p->H + 255) / 256;
   switch (nch) {
     case 1: hipLaunchKernelGGL((ln_fwd_kernel<1>), dim3(blocks), dim3(256), 0, stream, *p); break;
@@ -441,6 +451,7 @@ extern "C" int plb_launch_ln_fwd(const PlbLayerNorm* p, hipStream_t stream) {
 }
 extern "C" int plb_launch_ln_bwd(const PlbLayerNorm* p, hipStream_t stream) {
   if (p->H % 4 || p->H > 1024 || p->T <= 0 || p->nblocks <= 0) return 1;
+  ProfScope ps(PLB_K_LN_BWD, stream, 0, (double)p->T * (6.0 * p->H + 8));
   const int nch = (p->H + 255) / 256;
   switch (nch) {
     case 1: hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(p->nblocks), dim3(256), 0, stream, *p); break;
@@ -454,6 +465,7 @@ extern "C" int plb_launch_reduce_slabs(const float* slab, int splits, size_t n, 
                                        hipStream_t stream) {
   if (!n) return 0;
   const size_t threads = (n + 3) / 4;
+  ProfScope ps(PLB_K_REDUCE, stream, 0, 4.0 * (double)n * (splits + 1));
   hipLaunchKernelGGL(reduce_slabs_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, slab, splits, n,
                      out, accumulate);
   return LAUNCH_OK();
@@ -461,6 +473,7 @@ extern "C" int plb_launch_reduce_slabs(const float* slab, int splits, size_t n, 
 extern "C" int plb_launch_colsum(const void* X, int is_bf16, size_t R, int N, int ld, float* out, int Nout,
                                  int accumulate, float* scratch, int nsplit, hipStream_t stream) {
   if (N % 8 || ld % 8 || nsplit <= 0 || Nout > N) return 1;
+  ProfScope ps(PLB_K_COLSUM, stream, 0, (double)R * N * (is_bf16 ? 2 : 4));
   dim3 grid((N + 255) / 256, nsplit);
   if (is_bf16) hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, stream, X, R, N, ld, scratch, nsplit);
   else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, stream, X, R, N, ld, scratch, nsplit);
@@ -473,6 +486,7 @@ extern "C" int plb_launch_colsum(const void* X, int is_bf16, size_t R, int N, in
 extern "C" int plb_launch_gather_rows(const bf16_t* src, int lds_, const int32_t* rows, int n, int npad, int H,
                                       bf16_t* dst, int ldd, hipStream_t stream) {
   if (H % 8 || npad <= 0) return 1;
+  ProfScope ps(PLB_K_ROWS, stream, 0, 4.0 * (double)npad * H);
   hipLaunchKernelGGL(gather_rows_kernel, dim3(npad), dim3(128), 0, stream, src, lds_, rows, n, npad, H, dst, ldd);
   return LAUNCH_OK();
 }
@@ -480,7 +494,8 @@ extern "C" int plb_launch_scatter_rows(const bf16_t* src, int lds_, const int32_
                                        int ldd, hipStream_t stream) {
   if (H % 8) return 1;
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3(n), dim3(128), 0, stream, src, lds_, rows, n, H, dst, ldd);
+  hipLaunchKernelGGL(scatter_rows_kernel
+, dim3(n), dim3(128), 0, stream, src, lds_, rows, n, H, dst, ldd);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_ce_prepare(const int32_t* offsets, const int32_t* flat, const int64_t* labels, int B, int S,
@@ -491,6 +506,7 @@ extern "C" int plb_launch_ce_prepare(const int32_t* offsets, const int32_t* flat
 extern "C" int plb_launch_ce_fwd_bwd(const float* logits, int ldl, int V, const int32_t* tgt, const float* w, int n,
                                      int npad, float* loss_rows, bf16_t* dlogits, int ldd, hipStream_t stream) {
   if (V > 256 || ldd > 256 || ldd % 4 || npad <= 0) return 1;
+  ProfScope ps(PLB_K_CE, stream, 0, (double)npad * (4.0 * V + 2.0 * ldd));
   hipLaunchKernelGGL(ce_kernel, dim3((npad + 3) / 4), dim3(256), 0, stream, logits, ldl, V, tgt, w, n, npad, loss_rows,
                      dlogits, ldd);
   return LAUNCH_OK();
@@ -504,6 +520,7 @@ extern "C" int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf
                                 hipStream_t stream) {
   if (n % 4 || step < 1) return 1;
   if (!n) return 0;
+  ProfScope ps(PLB_K_ADAMW, stream, 0, (double)n * 30.0);  // p,m,v read+write, g read, bf16 copy
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, p_bf16, n, lr,
                      beta1, beta2, eps, wd, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
@@ -511,10 +528,12 @@ extern "C" int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf
 }
 extern "C" int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream) {
   if (!n) return 0;
+  ProfScope ps(PLB_K_CAST, stream, 0, 6.0 * (double)n);
   hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, dst, n);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_transpose_cast(const float* src, int R, int C, bf16_t* dst, int ldd, hipStream_t stream) {
+  ProfScope ps(PLB_K_CAST, stream, 0, 6.0 * (double)R * C);
   hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, src, R, C, dst, ldd);
   return LAUNCH_OK();
 }
