@@ -110,34 +110,36 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(PlbAttn p) {
 
   const int nkt = (len + 63) >> 6;
   const int sr = tid >> 3, sc = tid & 7;  // staging: 32 rows x 8 chunks, 2 passes
-  uint4 kr[2], vr[2];
-  auto load_kv = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key = kt * 64 + sr + 32 * i; key = key < S ? key : S - 1;
-      kr[i] = *(const uint4*)(kbase + (tok0 + key) * ld + sc * 8);
-      vr[i] = *(const uint4*)(vbase + (tok0 + key) * ld + sc * 8);
-    }
-  };
-  auto store_kv = [&](int st) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = sr + 32 * i;
-      *(uint4*)&smem[st][0][row_off(r, sc)] = kr[i];
-      *(uint4*)&smem[st][1][tr_off(r, sc * 8)] = vr[i];
-    }
-  };
+  // staging registers are named scalars and every iteration loads/stores unconditionally (the
+  // last one re-loads its own tile): arrays captured by lambdas were demoted to scratch.
+  uint4 kr0, kr1, vr0, vr1;
+  const int so_r0 = row_off(sr, sc), so_r1 = row_off(sr + 32, sc);
+  const int so_t0 = tr_off(sr, sc * 8), so_t1 = tr_off(sr + 32, sc * 8);
+#define KV_LOAD(kt_)                                                        \
+  do {                                                                      \
+    int k0_ = (kt_) * 64 + sr, k1_ = k0_ + 32;                              \
+    k0_ = k0_ < S ? k0_ : S - 1; k1_ = k1_ < S ? k1_ : S - 1;               \
+    kr0 = *(const uint4*)(kbase + (tok0 + k0_) * ld + sc * 8);              \
+    kr1 = *(const uint4*)(kbase + (tok0 + k1_) * ld + sc * 8);              \
+    vr0 = *(const uint4*)(vbase + (tok0 + k0_) * ld + sc * 8);              \
+    vr1 = *(const uint4*)(vbase + (tok0 + k1_) * ld + sc * 8);              \
+  } while (0)
+#define KV_STORE(st_)                                                       \
+  do {                                                                      \
+    *(uint4*)&smem[st_][0][so_r0] = kr0; *(uint4*)&smem[st_][0][so_r1] = kr1; \
+    *(uint4*)&smem[st_][1][so_t0] = vr0; *(uint4*)&smem[st_][1][so_t1] = vr1; \
+  } while (0)
 
   f32x16 o0 = zero16(), o1 = zero16();
   float m_run = -INFINITY, l_run = 0.f;
   const float sl2 = p.scale * LOG2E;
 
-  load_kv(0);
-  store_kv(0);
+  KV_LOAD(0);
+  KV_STORE(0);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nkt) load_kv(kt + 1);
+    KV_LOAD(kt + 1 < nkt ? kt + 1 : kt);
     const bf16_t* sK = smem[cur][0];
     const bf16_t* sV = smem[cur][1];
     f32x16 s0 = zero16(), s1 = zero16();
@@ -176,9 +178,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(PlbAttn p) {
       o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, s4 >> 1, s4 & 1, 0, lane), pb, o0, 0, 0, 0);
       o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, s4 >> 1, s4 & 1, 1, lane), pb, o1, 0, 0, 0);
     }
-    if (kt + 1 < nkt) store_kv(cur ^ 1);
+    KV_STORE(cur ^ 1);
     __syncthreads();
   }
+#undef KV_LOAD
+#undef KV_STORE
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   if (h == 0 && q0 + lq < S)
@@ -230,32 +234,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(PlbAttn p) {
 
   const int nkt = (len + 63) >> 6;
   const int sr = tid >> 3, sc = tid & 7;
-  uint4 kr[2], vr[2];
-  auto load_kv = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int key = kt * 64 + sr + 32 * i; key = key < S ? key : S - 1;
-      kr[i] = *(const uint4*)(kbase + (tok0 + key) * ld + sc * 8);
-      vr[i] = *(const uint4*)(vbase + (tok0 + key) * ld + sc * 8);
-    }
-  };
-  auto store_kv = [&](int st) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = sr + 32 * i;
-      *(uint4*)&smem[st][0][row_off(r, sc)] = kr[i];
-      *(uint4*)&smem[st][1][tr_off(r, sc * 8)] = kr[i];
-      *(uint4*)&smem[st][2][row_off(r, sc)] = vr[i];
-    }
-  };
+  uint4 kr0, kr1, vr0, vr1;
+  const int so_r0 = row_off(sr, sc), so_r1 = row_off(sr + 32, sc);
+  const int so_t0 = tr_off(sr, sc * 8), so_t1 = tr_off(sr + 32, sc * 8);
+#define KV_LOAD(kt_)                                                        \
+  do {                                                                      \
+    int k0_ = (kt_) * 64 + sr, k1_ = k0_ + 32;                              \
+    k0_ = k0_ < S ? k0_ : S - 1; k1_ = k1_ < S ? k1_ : S - 1;               \
+    kr0 = *(const uint4*)(kbase + (tok0 + k0_) * ld + sc * 8);              \
+    kr1 = *(const uint4*)(kbase + (tok0 + k1_) * ld + sc * 8);              \
+    vr0 = *(const uint4*)(vbase + (tok0 + k0_) * ld + sc * 8);              \
+    vr1 = *(const uint4*)(vbase + (tok0 + k1_) * ld + sc * 8);              \
+  } while (0)
+#define KV_STORE(st_)                                                       \
+  do {                                                                      \
+    *(uint4*)&smem[st_][0][so_r0] = kr0; *(uint4*)&smem[st_][0][so_r1] = kr1; \
+    *(uint4*)&smem[st_][1][so_t0] = kr0; *(uint4*)&smem[st_][1][so_t1] = kr1; \
+    *(uint4*)&smem[st_][2][so_r0] = vr0; *(uint4*)&smem[st_][2][so_r1] = vr1; \
+  } while (0)
 
   f32x16 dq0 = zero16(), dq1 = zero16();
-  load_kv(0);
-  store_kv(0);
+  KV_LOAD(0);
+  KV_STORE(0);
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nkt) load_kv(kt + 1);
+    KV_LOAD(kt + 1 < nkt ? kt + 1 : kt);
     const bf16_t* sK = smem[cur][0];
     const bf16_t* sKt = smem[cur][1];
     const bf16_t* sV = smem[cur][2];
@@ -281,9 +285,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(PlbAttn p) {
         dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sKt, kb, s2, 1, lane), dsb, dq1, 0, 0, 0);
       }
     }
-    if (kt + 1 < nkt) store_kv(cur ^ 1);
+    KV_STORE(cur ^ 1);
     __syncthreads();
   }
+#undef KV_LOAD
+#undef KV_STORE
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
   int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
   if (rows_valid > 0)
@@ -323,42 +329,41 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(PlbAttn p) {
   // queries past the length carry exactly zero dO in this model (no loss there), so tiles stop at len
   const int nqt = (blockIdx.x * 128 < len) ? ((len + 63) >> 6) : 0;
   const int sr = tid >> 3, sc = tid & 7;
-  uint4 qr[2], dr[2];
+  uint4 qr0, qr1, dr0, dr1;
   float st_l = 0.f, st_d = 0.f;
   const bf16_t* qbase = p.qkv + hd * 64;
   const bf16_t* dobase = p.dctx + hd * 64;
   const size_t statb = ((size_t)b * p.NH + hd) * S;
-  auto load_q = [&](int qt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int q = qt * 64 + sr + 32 * i; q = q < S ? q : S - 1;
-      qr[i] = *(const uint4*)(qbase + (tok0 + q) * ld + sc * 8);
-      dr[i] = *(const uint4*)(dobase + (tok0 + q) * p.lddctx + sc * 8);
-    }
-    if (tid < 64) {
-      int q = qt * 64 + tid; q = q < S ? q : S - 1;
-      st_l = p.lse[statb + q] * LOG2E;
-      st_d = p.delta[statb + q];
-    }
-  };
-  auto store_q = [&](int st) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int r = sr + 32 * i;
-      *(uint4*)&smem[st][0][row_off(r, sc)] = qr[i];
-      *(uint4*)&smem[st][1][tr_off(r, sc * 8)] = qr[i];
-      *(uint4*)&smem[st][2][row_off(r, sc)] = dr[i];
-      *(uint4*)&smem[st][3][tr_off(r, sc * 8)] = dr[i];
-    }
-    if (tid < 64) { sstat[st][0][tid] = st_l; sstat[st][1][tid] = st_d; }
-  };
+  const int so_r0 = row_off(sr, sc), so_r1 = row_off(sr + 32, sc);
+  const int so_t0 = tr_off(sr, sc * 8), so_t1 = tr_off(sr + 32, sc * 8);
+  const int stq = tid & 63;  // every wave loads the 64 row statistics; wave 0 stores them
+#define Q_LOAD(qt_)                                                         \
+  do {                                                                      \
+    int q0_ = (qt_) * 64 + sr, q1_ = q0_ + 32;                              \
+    q0_ = q0_ < S ? q0_ : S - 1; q1_ = q1_ < S ? q1_ : S - 1;               \
+    qr0 = *(const uint4*)(qbase + (tok0 + q0_) * ld + sc * 8);              \
+    qr1 = *(const uint4*)(qbase + (tok0 + q1_) * ld + sc * 8);              \
+    dr0 = *(const uint4*)(dobase + (tok0 + q0_) * p.lddctx + sc * 8);       \
+    dr1 = *(const uint4*)(dobase + (tok0 + q1_) * p.lddctx + sc * 8);       \
+    int qs_ = (qt_) * 64 + stq; qs_ = qs_ < S ? qs_ : S - 1;                \
+    st_l = p.lse[statb + qs_] * LOG2E;                                      \
+    st_d = p.delta[statb + qs_];                                            \
+  } while (0)
+#define Q_STORE(st_)                                                        \
+  do {                                                                      \
+    *(uint4*)&smem[st_][0][so_r0] = qr0; *(uint4*)&smem[st_][0][so_r1] = qr1; \
+    *(uint4*)&smem[st_][1][so_t0] = qr0; *(uint4*)&smem[st_][1][so_t1] = qr1; \
+    *(uint4*)&smem[st_][2][so_r0] = dr0; *(uint4*)&smem[st_][2][so_r1] = dr1; \
+    *(uint4*)&smem[st_][3][so_t0] = dr0; *(uint4*)&smem[st_][3][so_t1] = dr1; \
+    if (tid < 64) { sstat[st_][0][tid] = st_l; sstat[st_][1][tid] = st_d; }  \
+  } while (0)
 
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-  if (nqt > 0) { load_q(0); store_q(0); }
+  if (nqt > 0) { Q_LOAD(0); Q_STORE(0); }
   __syncthreads();
   for (int qt = 0; qt < nqt; ++qt) {
     const int cur = qt & 1;
-    if (qt + 1 < nqt) load_q(qt + 1);
+    Q_LOAD(qt + 1 < nqt ? qt + 1 : qt);
     const bf16_t* sQ = smem[cur][0];
     const bf16_t* sQt = smem[cur][1];
     const bf16_t* sDO = smem[cur][2];
@@ -397,9 +402,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(PlbAttn p) {
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQt, qb, s2, 1, lane), dsb, dk1, 0, 0, 0);
       }
     }
-    if (qt + 1 < nqt) store_q(cur ^ 1);
+    Q_STORE(cur ^ 1);
     __syncthreads();
   }
+#undef Q_LOAD
+#undef Q_STORE
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
   int rows_valid = S - key0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
   if (rows_valid > 0) {

@@ -35,23 +35,27 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(PlbGemmNT p) {
   const int lr = tid >> 3, lc = tid & 7;  // staging: 32 rows x 8 chunks per pass, 4 passes
   const bf16_t* gA = p.A + (size_t)(bm * BM + lr) * p.lda + lc * 8;
   const bf16_t* gB = p.B + (size_t)(bn * BN + lr) * p.ldb + lc * 8;
-  uint4 ra[4], rb[4];
-
-  auto load_tile = [&](int kt) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      ra[i] = *(const uint4*)(gA + (size_t)(32 * i) * p.lda + kt * BK);
-      rb[i] = *(const uint4*)(gB + (size_t)(32 * i) * p.ldb + kt * BK);
-    }
-  };
-  auto store_tile = [&](int st) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int row = lr + 32 * i;
-      *(uint4*)&smem[st][0][nt_lds_off(row, lc)] = ra[i];
-      *(uint4*)&smem[st][1][nt_lds_off(row, lc)] = rb[i];
-    }
-  };
+  const size_t sa = (size_t)32 * p.lda, sb = (size_t)32 * p.ldb;
+  // staging registers are named scalars (arrays captured by lambdas were demoted to scratch)
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define NT_LOAD(kt)                                                           \
+  do {                                                                        \
+    const bf16_t* a_ = gA + (size_t)(kt) * BK;                                \
+    const bf16_t* b_ = gB + (size_t)(kt) * BK;                                \
+    ra0 = *(const uint4*)(a_); ra1 = *(const uint4*)(a_ + sa);                \
+    ra2 = *(const uint4*)(a_ + 2 * sa); ra3 = *(const uint4*)(a_ + 3 * sa);   \
+    rb0 = *(const uint4*)(b_); rb1 = *(const uint4*)(b_ + sb);                \
+    rb2 = *(const uint4*)(b_ + 2 * sb); rb3 = *(const uint4*)(b_ + 3 * sb);   \
+  } while (0)
+  const int so0 = nt_lds_off(lr, lc), so1 = nt_lds_off(lr + 32, lc), so2 = nt_lds_off(lr + 64, lc),
+            so3 = nt_lds_off(lr + 96, lc);
+#define NT_STORE(st)                                                          \
+  do {                                                                        \
+    *(uint4*)&smem[st][0][so0] = ra0; *(uint4*)&smem[st][0][so1] = ra1;       \
+    *(uint4*)&smem[st][0][so2] = ra2; *(uint4*)&smem[st][0][so3] = ra3;       \
+    *(uint4*)&smem[st][1][so0] = rb0; *(uint4*)&smem[st][1][so1] = rb1;       \
+    *(uint4*)&smem[st][1][so2] = rb2; *(uint4*)&smem[st][1][so3] = rb3;       \
+  } while (0)
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -59,34 +63,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(PlbGemmNT p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
   const int frow = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
+  // (row>>1)&7 of a fragment row depends on the lane only: rows are wr*64 + i*16 + frow
+  const int fsw = (frow >> 1) & 7;
+  const int offA = (wr * 64 + frow) * BK, offB = (wc * 64 + frow) * BK;
+#define NT_COMPUTE(st)                                                                                   \
+  do {                                                                                                   \
+    const bf16_t* sA = smem[st][0];                                                                      \
+    const bf16_t* sB = smem[st][1];                                                                      \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk) {                                                   \
+      const int ch = ((kk * 4 + fq) ^ fsw) << 3;                                                         \
+      bf16x8 af[4], bfr[4];                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+        af[i] = *(const bf16x8*)&sA[offA + i * 16 * BK + ch];                                            \
+        bfr[i] = *(const bf16x8*)&sB[offB + i * 16 * BK + ch];                                           \
+      }                                                                                                  \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                   \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                 \
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);  \
+    }                                                                                                    \
+  } while (0)
+
+  // swapped MFMA operands: D[row = n][col = m], so each lane owns 4 consecutive n of one row m
+  const int nk = p.K / BK;
+  NT_LOAD(0);
+  NT_STORE(0);
+  __syncthreads();
+  int kt = 0;
+  for (; kt + 1 < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
-    const bf16_t* sA = smem[cur][0];
-    const bf16_t* sB = smem[cur][1];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 af[4], bfr[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *(const bf16x8*)&sA[nt_lds_off(wr * 64 + i * 16 + frow, kk * 4 + fq)];
-        bfr[i] = *(const bf16x8*)&sB[nt_lds_off(wc * 64 + i * 16 + frow, kk * 4 + fq)];
-      }
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-          // swapped operands: D[row = n][col = m] so each lane owns 4 consecutive n of one row m
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ni], af[mi], acc[mi][ni], 0, 0, 0);
-    }
-    if (kt + 1 < nk) store_tile(cur ^ 1);
+    NT_LOAD(kt + 1);
+    NT_COMPUTE(cur);
+    NT_STORE(cur ^ 1);
     __syncthreads();
   }
+  NT_COMPUTE(kt & 1);
+#undef NT_LOAD
+#undef NT_STORE
+#undef NT_COMPUTE
 
   // epilogue: lane holds C[m][n0..n0+3]
 #pragma unroll
