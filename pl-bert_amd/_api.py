@@ -5,7 +5,25 @@ from .init import param_shapes, deterministic_state_dict, reference_init_state_d
 from .data import (MaskedPhonemeDataset, PhonemeOnlyCollater, Collater, build_dataloader,
                    length_to_mask, masked_indices_to_csr, synthetic_batch, seed_reference_streams)
 
+
+
+def __getattr__(name):
+    # GPU-backed classes import torch.cuda-facing modules lazily so that the host-only parts of the
+    # package (data path, config, layout) stay importable on machines without the HIP library.
+    if name in ("AlbertModel", "PhonemeOnlyModel", "MultiTaskModel", "BaseModelOutputWithPooling"):
+        from . import model
+        return getattr(model, name)
+    if name in ("PLBertTrainer", "process_batch", "AdamW", "StagedBatch", "stage_reference_batch", "validate_batch"):
+        from . import train
+        return getattr(train, name)
+    if name == "HipEngine":
+        from .engine import HipEngine
+        return HipEngine
+    raise AttributeError(name)
+
+
 __all__ = [
+    "AlbertModel", "PhonemeOnlyModel", "MultiTaskModel", "PLBertTrainer", "process_batch", "AdamW", "HipEngine",
     "AlbertConfig", "albert_config_from_yaml", "load_config",
     "CharacterIndexer", "symbols", "PAD_ID", "MASK_ID", "SEPARATOR_ID", "UNKNOWN_ID",
     "param_shapes", "deterministic_state_dict", "reference_init_state_dict",

@@ -240,7 +240,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   e->o_part1 = cv.take(L * e->ln_blocks * 2 * H * 4);
   e->o_part2 = cv.take(L * e->ln_blocks * 2 * H * 4);
   e->o_parte = cv.take((int64_t)e->emb_blocks * 2 * E * 4);
-  e->o_scratch = cv.take(64 * (3 * H > I ? 3 * H : I) * 4);
+  e->o_scratch = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);  // colsum partials: up to 512 row splits
   e->ws_bytes = cv.off;
   *out = e;
   return 0;
@@ -539,7 +539,7 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   g.C = de; g.ldc = E;
   TRY(plb_launch_gemm_nt(&g, 0, 0, s));
   if (weight_grad(e, dy, H, H, evec, E, Tp, H, E, e->grd(PLB_MAP_W), s)) return 1;
-  TRY(plb_launch_colsum(dy, 1, (size_t)Tp, H, H, e->grd(PLB_MAP_B), H, 0, scratch, 32, s));
+  TRY(plb_launch_colsum(dy, 1, (size_t)Tp, H, H, e->grd(PLB_MAP_B), H, 0, scratch, 128, s));
   HIPTRY(hipMemsetAsync(e->grd(PLB_WORD_EMB), 0, (size_t)(e->psize[PLB_WORD_EMB] + e->psize[PLB_POS_EMB] + e->psize[PLB_TYPE_EMB]) * 4, s));
   PlbEmbed em;
   memset(&em, 0, sizeof(em));
@@ -559,10 +559,10 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   if (weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dqkv), 1, (size_t)Mtot, 3 * H, 3 * H, e->grd(PLB_Q_B), 3 * H, 0, scratch, 64, s));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre1), 1, (size_t)Mtot, H, H, e->grd(PLB_DENSE_B), H, 0, scratch, 64, s));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 64, s));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre2), 1, (size_t)Mtot, H, H, e->grd(PLB_FFNO_B), H, 0, scratch, 64, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dqkv), 1, (size_t)Mtot, 3 * H, 3 * H, e->grd(PLB_Q_B), 3 * H, 0, scratch, 128, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre1), 1, (size_t)Mtot, H, H, e->grd(PLB_DENSE_B), H, 0, scratch, 384, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 128, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre2), 1, (size_t)Mtot, H, H, e->grd(PLB_FFNO_B), H, 0, scratch, 384, s));
   TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, (size_t)L * e->ln_blocks, 2 * H, 2 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch, 16, s));
   TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, (size_t)L * e->ln_blocks, 2 * H, 2 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch, 16, s));
   return 0;

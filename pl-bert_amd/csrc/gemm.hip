@@ -8,8 +8,8 @@
 //            operands are token-major, so fragments come from transposed LDS reads).
 //
 // Tile 128x128, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA 16x16x32 tiles, fp32
-// accumulate. Operands are staged global -> registers -> LDS (double buffered, one barrier per
-// k-tile); LDS images are XOR-swizzled / strip-rotated so ds_read_b128 / ds_read_b64_tr_b16 and
+// accumulate. NT operands are staged by LDS-DMA (global_load_lds), TN operands through registers
+// (double buffered, one barrier per k-tile); LDS images are XOR-swizzled / strip-rotated so ds_read_b128 / ds_read_b64_tr_b16 and
 // the ds_write_b128 staging stores are bank-conflict free.
 #include "common.h"
 #include "plbert_kernels.h"
@@ -32,30 +32,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(PlbGemmNT p) {
   const int logical = xcd_remap(blockIdx.x, nwg);
   const int bm = logical / nbn, bn = logical % nbn;
 
-  const int lr = tid >> 3, lc = tid & 7;  // staging: 32 rows x 8 chunks per pass, 4 passes
-  const bf16_t* gA = p.A + (size_t)(bm * BM + lr) * p.lda + lc * 8;
-  const bf16_t* gB = p.B + (size_t)(bn * BN + lr) * p.ldb + lc * 8;
-  const size_t sa = (size_t)32 * p.lda, sb = (size_t)32 * p.ldb;
-  // staging registers are named scalars (arrays captured by lambdas were demoted to scratch)
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-#define NT_LOAD(kt)                                                           \
-  do {                                                                        \
-    const bf16_t* a_ = gA + (size_t)(kt) * BK;                                \
-    const bf16_t* b_ = gB + (size_t)(kt) * BK;                                \
-    ra0 = *(const uint4*)(a_); ra1 = *(const uint4*)(a_ + sa);                \
-    ra2 = *(const uint4*)(a_ + 2 * sa); ra3 = *(const uint4*)(a_ + 3 * sa);   \
-    rb0 = *(const uint4*)(b_); rb1 = *(const uint4*)(b_ + sb);                \
-    rb2 = *(const uint4*)(b_ + 2 * sb); rb3 = *(const uint4*)(b_ + 3 * sb);   \
+  // Staging: LDS-DMA (global_load_lds, 16 B per lane). One wave-instruction fills 8 rows x 128 B of
+  // the image; the destination is wave-uniform base + lane*16, so the XOR swizzle is applied to the
+  // per-lane SOURCE chunk (row r, stored chunk c' <- global chunk c' ^ ((r>>1)&7)). Each wave stages
+  // rows [32w, 32w+32) of A and of B: 8 DMA instructions per k-tile, no VGPR round trip.
+  const int uw = __builtin_amdgcn_readfirstlane(wave);
+  const int drow = lane >> 3, dch = lane & 7;
+  const bf16_t* gA = p.A + (size_t)(bm * BM + uw * 32 + drow) * p.lda;
+  const bf16_t* gB = p.B + (size_t)(bn * BN + uw * 32 + drow) * p.ldb;
+  const size_t sa = (size_t)8 * p.lda, sb = (size_t)8 * p.ldb;
+  int sch[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sch[i] = (dch ^ ((4 * i + (lane >> 4)) & 7)) * 8;
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+#define NT_STAGE(st, kt)                                                                              \
+  do {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gA + i * sa + (size_t)(kt) * BK + sch[i]),            \
+                                       (lptr_t)&smem[st][0][(uw * 32 + i * 8) * BK], 16, 0, 0);       \
+      __builtin_amdgcn_global_load_lds((gptr_t)(gB + i * sb + (size_t)(kt) * BK + sch[i]),            \
+                                       (lptr_t)&smem[st][1][(uw * 32 + i * 8) * BK], 16, 0, 0);       \
+    }                                                                                                 \
   } while (0)
-  const int so0 = nt_lds_off(lr, lc), so1 = nt_lds_off(lr + 32, lc), so2 = nt_lds_off(lr + 64, lc),
-            so3 = nt_lds_off(lr + 96, lc);
-#define NT_STORE(st)                                                          \
-  do {                                                                        \
-    *(uint4*)&smem[st][0][so0] = ra0; *(uint4*)&smem[st][0][so1] = ra1;       \
-    *(uint4*)&smem[st][0][so2] = ra2; *(uint4*)&smem[st][0][so3] = ra3;       \
-    *(uint4*)&smem[st][1][so0] = rb0; *(uint4*)&smem[st][1][so1] = rb1;       \
-    *(uint4*)&smem[st][1][so2] = rb2; *(uint4*)&smem[st][1][so3] = rb3;       \
-  } while (0)
+#define NT_LANDED() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -86,20 +86,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(PlbGemmNT p) {
 
   // swapped MFMA operands: D[row = n][col = m], so each lane owns 4 consecutive n of one row m
   const int nk = p.K / BK;
-  NT_LOAD(0);
-  NT_STORE(0);
+  NT_STAGE(0, 0);
+  NT_LANDED();
   __syncthreads();
-  int kt = 0;
-  for (; kt + 1 < nk; ++kt) {
+  for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    NT_LOAD(kt + 1);
-    NT_COMPUTE(cur);
-    NT_STORE(cur ^ 1);
+    if (kt + 1 < nk) NT_STAGE(cur ^ 1, kt + 1);  // buffer cur^1 was last read before the previous barrier
+    NT_COMPUTE(cur);  // one copy of the MFMA body: a peeled last iteration made the allocator shuffle AGPRs
+    NT_LANDED();
     __syncthreads();
   }
-  NT_COMPUTE(kt & 1);
-#undef NT_LOAD
-#undef NT_STORE
+#undef NT_STAGE
+#undef NT_LANDED
 #undef NT_COMPUTE
 
   // epilogue: lane holds C[m][n0..n0+3]

@@ -300,22 +300,22 @@ __global__ void scatter_rows_kernel(const bf16_t* src, int lds_, const int32_t* 
 // the samples that have any. One thread per sample.
 __global__ void ce_prepare_kernel(const int32_t* offsets, const int32_t* flat, const int64_t* labels, int B, int S,
                                   int32_t* rows, int32_t* tgt, float* w) {
-  __shared__ int count;
-  if (threadIdx.x == 0) {
-    int c = 0;
-    for (int b = 0; b < B; ++b) c += offsets[b + 1] > offsets[b];
-    count = c;
-  }
+  // one block per sample; every block counts the non-empty samples itself (B is small)
+  __shared__ int cnt[4];
+  int c = 0;
+  for (int b = threadIdx.x; b < B; b += blockDim.x) c += offsets[b + 1] > offsets[b];
+  c = (int)wave_sum((float)c);
+  if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = c;
   __syncthreads();
-  for (int b = threadIdx.x; b < B; b += blockDim.x) {
-    const int j0 = offsets[b], j1 = offsets[b + 1];
-    const float wb = (j1 > j0) ? 1.0f / ((float)(j1 - j0) * (float)count) : 0.f;
-    for (int j = j0; j < j1; ++j) {
-      const int idx = flat[j];
-      rows[j] = b * S + idx;
-      tgt[j] = (int32_t)labels[(size_t)b * S + idx];
-      w[j] = wb;
-    }
+  const int count = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+  const int b = blockIdx.x;
+  const int j0 = offsets[b], j1 = offsets[b + 1];
+  const float wb = (j1 > j0) ? 1.0f / ((float)(j1 - j0) * (float)count) : 0.f;
+  for (int j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+    const int idx = flat[j];
+    rows[j] = b * S + idx;
+    tgt[j] = (int32_t)labels[(size_t)b * S + idx];
+    w[j] = wb;
   }
 }
 // nn.CrossEntropyLoss on one row per wave: V <= 256 classes, 4 per lane.
@@ -500,7 +500,7 @@ extern "C" int plb_launch_scatter_rows(const bf16_t* src, int lds_, const int32_
 }
 extern "C" int plb_launch_ce_prepare(const int32_t* offsets, const int32_t* flat, const int64_t* labels, int B, int S,
                                      int32_t* rows, int32_t* tgt, float* w, hipStream_t stream) {
-  hipLaunchKernelGGL(ce_prepare_kernel, dim3(1), dim3(256), 0, stream, offsets, flat, labels, B, S, rows, tgt, w);
+  hipLaunchKernelGGL(ce_prepare_kernel, dim3(B), dim3(256), 0, stream, offsets, flat, labels, B, S, rows, tgt, w);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_ce_fwd_bwd(const float* logits, int ldl, int V, const int32_t* tgt, const float* w, int n,

@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from .data import masked_indices_to_csr
+from .dist import GradReducer
 from .engine import HipEngine
 from .init import reference_init_state_dict
 
@@ -63,15 +64,13 @@ class PLBertTrainer:
         self.engine = HipEngine(cfg, num_phonemes, 0, max_batch=max_batch, max_seq=max_seq, device=device)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.reducer = GradReducer(process_group, device=self.engine.device)
+        self.world = self.reducer.world
         sd = state_dict if state_dict is not None else reference_init_state_dict(cfg, num_phonemes, 0, seed=seed)
         self.engine.load_state_dict(sd)
         if self.world > 1:  # DDP's start-up broadcast of rank 0's parameters
-            dist.broadcast(self.engine.params, src=dist.get_global_rank(process_group, 0) if process_group else 0,
-                           group=process_group)
+            self.reducer.broadcast_(self.engine.params)
             self.engine.sync_weights()
-        self._comm_stream = torch.cuda.Stream(device=self.engine.device) if self.world > 1 else None
 
     def stage_batch(self, labels, masked, lengths, masked_indices, validate=True):
         if validate:
@@ -93,13 +92,7 @@ class PLBertTrainer:
     def all_reduce_grads(self):
         """Sum the trainable gradient range over ranks on a side stream (RCCL over xGMI); the AdamW
         kernel applies the 1/world factor."""
-        if self.world == 1:
-            return
-        main = torch.cuda.current_stream(self.engine.device)
-        self._comm_stream.wait_stream(main)
-        with torch.cuda.stream(self._comm_stream):
-            dist.all_reduce(self.engine.grads[: self.engine.trainable], op=dist.ReduceOp.SUM, group=self.group)
-        main.wait_stream(self._comm_stream)
+        self.reducer.all_reduce_(self.engine.grads[: self.engine.trainable])
 
     def step(self, batch: StagedBatch):
         """zero_grad + backward + optimizer.step of train.py:355-357; returns the local loss (device)."""
@@ -111,3 +104,105 @@ class PLBertTrainer:
         self.engine.adamw_step(self.step_count, self.lr, self.betas, self.eps, self.weight_decay,
                                grad_scale=1.0 / self.world)
         return loss
+
+
+# ---- drop-in forms of the reference's step functions ---------------------------------------------------
+class _FusedLoss(torch.autograd.Function):
+    """Bridges the fused fwd+bwd call into autograd so the reference loop body
+    ``loss = process_batch(...); optimizer.zero_grad(); accelerator.backward(loss); optimizer.step()``
+    (train.py:352-357) runs unchanged: forward computes loss AND gradients in one engine call,
+    backward hands each Parameter its slice of the engine's flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, engine, names, batch, *params):
+        loss = engine.loss_fwd_bwd(batch.masked, batch.labels, batch.lengths, batch.offsets, batch.flat, batch.n_masked)
+        ctx.engine, ctx.names = engine, names
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        eng = ctx.engine
+        grads = []
+        for n in ctx.names:
+            off, size, shp = eng.layout[n]
+            g = eng.grads[off:off + size].view(shp) if off + size <= eng.trainable else None
+            grads.append(g)
+        # d(loss)/d(param) is already in the flat buffer; scale by the upstream gradient on the device
+        # (1.0 for loss.backward(); no host sync to find out)
+        eng.grads[: eng.trainable].mul_(grad_out)
+        return (None, None, None, *grads)
+
+
+def stage_reference_batch(engine, batch, validate=True):
+    """(labels, masked, lengths, masked_indices) as PhonemeOnlyCollater returns it -> StagedBatch."""
+    labels, masked, lengths, idx = batch
+    if validate:
+        validate_batch(labels, masked, lengths, idx, engine.cfg.vocab_size)
+    dev = engine.device
+    masked_t = torch.as_tensor(np.asarray(masked), dtype=torch.int64).to(dev)
+    labels_t = torch.as_tensor(np.asarray(labels), dtype=torch.int64).to(dev)
+    S = masked_t.shape[1]
+    lens = np.asarray(lengths, dtype=np.int32)
+    lengths_t = None if (lens == S).all() else torch.from_numpy(lens).to(dev)
+    off, flat = masked_indices_to_csr(idx)
+    return StagedBatch(masked_t, labels_t, lengths_t, torch.from_numpy(off).to(dev), torch.from_numpy(flat).to(dev),
+                       int(off[-1]), int(lens.sum()))
+
+
+def process_batch(model, batch, criterion=None, accelerator=None):
+    """train.py:381-390 — ``batch = (phoneme_labels, masked_phonemes, input_lengths, masked_indices)``.
+    ``criterion`` / ``accelerator`` are accepted for signature compatibility: the loss is the
+    reference's calculate_phoneme_loss with nn.CrossEntropyLoss() (train.py:107-131, 215), computed by
+    the HIP engine. Returns a 0-dim tensor; under autograd its ``backward()`` fills ``param.grad``."""
+    engine = model.engine
+    staged = batch if isinstance(batch, StagedBatch) else stage_reference_batch(engine, batch)
+    if staged.n_masked == 0:  # train.py:129
+        return torch.tensor(0.0, device=engine.device, requires_grad=True)
+    names, params = [], []
+    for n, p in model.named_parameters():
+        names.append(n)
+        params.append(p)
+    if torch.is_grad_enabled():
+        return _FusedLoss.apply(engine, names, staged, *params)
+    return engine.loss_fwd_bwd(staged.masked, staged.labels, staged.lengths, staged.offsets, staged.flat,
+                               staged.n_masked)[0].clone()
+
+
+class AdamW:
+    """``torch.optim.AdamW(model.parameters(), lr=...)`` of train.py:272 as one fused HIP launch over the
+    model's flat buffers. ``params`` must be the parameters of ONE plbert_amd model (it identifies the
+    engine); state_dict()/load_state_dict() carry step + both moments (train.py:417-421 'optimizer')."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, model=None):
+        self.param_list = list(params)
+        if model is None:
+            raise ValueError("pass model=<PhonemeOnlyModel|MultiTaskModel>: the fused optimizer updates the model's "
+                             "flat parameter buffer")
+        self.engine = model.engine
+        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.step_count = 0
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.param_list:
+            p.grad = None
+
+    def step(self):
+        # parameters without a gradient are skipped as torch does: a step with no gradient at all (the
+        # zero-loss fallback) changes nothing; otherwise the trainable range is updated in one launch
+        if all(p.grad is None for p in self.param_list):
+            return
+        self.step_count += 1
+        d = self.defaults
+        self.engine.adamw_step(self.step_count, d["lr"], d["betas"], d["eps"], d["weight_decay"], self.grad_scale)
+
+    def state_dict(self):
+        e = self.engine
+        return {"step": self.step_count, "exp_avg": e.exp_avg[: e.trainable].clone(),
+                "exp_avg_sq": e.exp_avg_sq[: e.trainable].clone(), "defaults": dict(self.defaults)}
+
+    def load_state_dict(self, sd):
+        e = self.engine
+        self.step_count = int(sd["step"])
+        e.exp_avg[: e.trainable].copy_(sd["exp_avg"])
+        e.exp_avg_sq[: e.trainable].copy_(sd["exp_avg_sq"])

@@ -1,0 +1,118 @@
+"""CPU checks of the boundary: the C-ABI library loads (against torch's HIP runtime) and exports
+every symbol include/plbert.h declares; host logic that needs no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import plbert_amd
+from plbert_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "plbert.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(plb_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    decl = _declared_symbols()
+    assert decl, "no declarations parsed"
+    assert sorted(decl) == sorted(_lib.PUBLIC_SYMBOLS)
+    for s in decl:
+        assert hasattr(L, s), s
+
+
+def test_one_hip_runtime_in_process():
+    _lib.lib()
+    maps = open("/proc/self/maps").read()
+    libs = set(re.findall(r"(\S*libamdhip64\S*)", maps))
+    assert len(libs) == 1, libs  # torch's; loading a second runtime would invalidate torch's stream handles
+
+
+def test_host_only_calls_and_layout():
+    """plb_create / plb_param_layout / plb_workspace_bytes touch no device."""
+    L = _lib.lib()
+    c = _lib.PlbConfig(188, 128, 768, 12, 2048, 12, 512, 2, 1e-12, 188, 0, 32, 512)
+    h = C.c_void_p()
+    assert L.plb_create(C.byref(c), C.byref(h)) == 0
+    offs = (C.c_int64 * _lib.PLB_NPARAM)()
+    sizes = (C.c_int64 * _lib.PLB_NPARAM)()
+    total, train = C.c_int64(), C.c_int64()
+    assert L.plb_param_layout(h, offs, sizes, C.byref(total), C.byref(train)) == 0
+    assert total.value == 6438332                      # SURVEY.md §8(a) parameter inventory
+    assert total.value - train.value == 590592         # the pooler, outside the AdamW range
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048)
+    shapes = plbert_amd.param_shapes(cfg, 188)
+    names = [n for n in _lib.PLB_PARAM_NAMES if n in shapes]
+    assert list(shapes.keys()) == names
+    for i, n in enumerate(_lib.PLB_PARAM_NAMES):
+        if n in shapes:
+            assert sizes[i] == int(np.prod(shapes[n])), n
+            assert offs[i] % 4 == 0
+    ws = L.plb_workspace_bytes(h)
+    assert 4e9 < ws < 12e9                              # ~20 KB/token/layer of stash + grads, 16384 tokens
+    L.plb_destroy(h)
+    # rejected configurations fail loudly with a message
+    bad = _lib.PlbConfig(188, 128, 768, 8, 2048, 12, 512, 2, 1e-12, 188, 0, 32, 512)
+    assert L.plb_create(C.byref(bad), C.byref(h)) != 0
+    assert b"head_dim" in L.plb_last_error()
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        plbert_amd.HipEngine(cfg, 188)
+    with pytest.raises(RuntimeError):
+        plbert_amd.AlbertModel(cfg)
+
+
+def test_config_yaml_surface(tmp_path):
+    y = tmp_path / "config.yml"
+    y.write_text("""
+model_params:
+  pretrained_model: ""
+  hidden_size: 768
+  num_attention_heads: 12
+  intermediate_size: 2048
+  max_position_embeddings: 512
+  num_hidden_layers: 12
+  dropout: 0.1
+dataset_params:
+  word_separator: 87
+  max_seq_length: 512
+  word_pred_prob: 0.15
+  phoneme_mask_prob: 0.8
+  replace_prob: 0.1
+""")
+    conf = plbert_amd.load_config(str(y))
+    cfg = plbert_amd.albert_config_from_yaml(conf, vocab_size=len(plbert_amd.symbols))
+    assert (cfg.vocab_size, cfg.embedding_size, cfg.hidden_size, cfg.num_hidden_layers) == (188, 128, 768, 12)
+    assert cfg.dropout == 0.1 and cfg.pretrained_model == "" and cfg.hidden_dropout_prob == 0.0  # inert extras
+    cfg.check_supported()
+    with pytest.raises(ValueError):
+        plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, hidden_act="gelu").check_supported()
+
+
+def test_validate_batch_rejects_bad_inputs():
+    from plbert_amd.train import validate_batch
+
+    lab = np.ones((2, 8), np.int64)
+    validate_batch(lab, lab, [8, 5], [[0, 1], [4]], 188)
+    with pytest.raises(ValueError):
+        validate_batch(lab, lab, [8, 5], [[0, 1], [5]], 188)      # index beyond the length
+    with pytest.raises(ValueError):
+        validate_batch(lab, lab, [8, 5], [[1, 1], [0]], 188)      # duplicate
+    with pytest.raises(ValueError):
+        validate_batch(lab * 200, lab, [8, 5], [[0], [0]], 188)   # id outside the vocabulary
+    with pytest.raises(ValueError):
+        validate_batch(lab, lab, [9, 5], [[0], [0]], 188)         # length beyond S

@@ -1,0 +1,101 @@
+"""Drop-in boundary (-m gpu): the reference-shaped classes and the reference loop body
+(train.py:350-357) running on the HIP engine, checked against goldens captured from the reference."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cfg, load_golden
+import plbert_amd
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(g, multitask=False):
+    ocfg, pcfg, sd = golden_cfg(g)
+    B, S = g["labels"].shape
+    enc = plbert_amd.AlbertModel(pcfg, max_batch=B, max_seq=S)
+    if multitask:
+        m = plbert_amd.MultiTaskModel(enc, num_phonemes=int(g["num_phonemes"]), num_tokens=int(g["num_tokens"]),
+                                      hidden_size=pcfg.hidden_size)
+    else:
+        m = plbert_amd.PhonemeOnlyModel(enc, num_phonemes=int(g["num_phonemes"]), hidden_size=pcfg.hidden_size)
+    # checkpoints written by DDP carry 'module.' prefixes; the reference strips them (train.py:98)
+    missing, unexpected = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not missing and not unexpected
+    return m, pcfg, sd
+
+
+def test_state_dict_names_and_shapes():
+    g = load_golden("small_h128_multitask")
+    m, pcfg, sd = _make(g, multitask=True)
+    got = m.state_dict()
+    assert set(got.keys()) == set(sd.keys())
+    for k, v in sd.items():
+        assert tuple(got[k].shape) == v.shape, k
+        assert np.array_equal(got[k].cpu().numpy(), v), k
+    assert sum(p.numel() for p in m.parameters()) == sum(v.size for v in sd.values())
+
+
+def test_forward_signatures_match_reference_outputs():
+    g = load_golden("small_h128_multitask")
+    m, pcfg, sd = _make(g, multitask=True)
+    ids = torch.from_numpy(g["masked"])
+    text_mask = plbert_amd.length_to_mask(torch.Tensor(g["lengths"].tolist()))
+    am = (~text_mask).int()
+    m.eval()
+    with torch.no_grad():
+        ph, tk = m(ids, attention_mask=am)
+        hid = m.encoder(ids, attention_mask=am).last_hidden_state
+    assert ph.dtype == torch.float32 and tuple(ph.shape) == g["logits"].shape
+    v = (am != 0).numpy()
+    assert np.abs(ph.cpu().numpy()[v] - g["logits"][v]).max() < 3e-2
+    assert np.abs(tk.cpu().numpy()[v] - g["token_logits"][v]).max() < 3e-2
+    assert np.abs(hid.cpu().numpy()[v] - g["hidden"][v]).max() < 6e-2
+    with pytest.raises(ValueError):
+        bad = am.clone()
+        bad[0, 3] = 0  # a hole: not a prefix mask
+        m(ids, attention_mask=bad)
+
+
+def test_reference_loop_body_runs_unchanged():
+    """loss = process_batch(...); optimizer.zero_grad(); loss.backward(); optimizer.step()"""
+    g = load_golden("small_h128")
+    m, pcfg, sd = _make(g)
+    opt = plbert_amd.AdamW(m.parameters(), lr=1e-3, model=m)
+    batch = (torch.from_numpy(g["labels"]), torch.from_numpy(g["masked"]), [int(x) for x in g["lengths"]],
+             [list(map(int, x)) for x in g["index"]])
+    m.train()
+    losses = []
+    for _ in g["losses"]:
+        loss = plbert_amd.process_batch(m, batch, criterion=torch.nn.CrossEntropyLoss(), accelerator=None)
+        opt.zero_grad()
+        loss.backward()
+        assert m.phoneme_predictor.weight.grad is not None and m.encoder.pooler.weight.grad is None
+        opt.step()
+        losses.append(float(loss.item()))
+    assert np.allclose(losses, g["losses"], rtol=2e-3)
+    # validation path (train.py:288-304): eval + no_grad gives a plain number and changes nothing
+    before = m.phoneme_predictor.weight.detach().clone()
+    m.eval()
+    with torch.no_grad():
+        vl = plbert_amd.process_batch(m, batch, None, None)
+    assert not vl.requires_grad and torch.equal(before, m.phoneme_predictor.weight.detach())
+    # optimizer state round trip ('optimizer' entry of the checkpoint dict, train.py:417-421)
+    st = opt.state_dict()
+    opt2 = plbert_amd.AdamW(m.parameters(), lr=1e-3, model=m)
+    opt2.load_state_dict(st)
+    assert opt2.step_count == opt.step_count
+
+
+def test_standalone_encoder_loads_stripped_checkpoint():
+    """README.md:49-66 consumer: strip 'module.' and 'encoder.' and load into AlbertModel."""
+    g = load_golden("small_h128")
+    ocfg, pcfg, sd = golden_cfg(g)
+    enc = plbert_amd.AlbertModel(pcfg, max_batch=3, max_seq=40)
+    stripped = {k[len("encoder."):]: torch.from_numpy(v) for k, v in sd.items() if k.startswith("encoder.")}
+    enc.load_state_dict(stripped, strict=False)
+    am = (~plbert_amd.length_to_mask(torch.Tensor(g["lengths"].tolist()))).int()
+    out = enc(torch.from_numpy(g["masked"]), attention_mask=am)
+    v = (am != 0).numpy()
+    assert np.abs(out.last_hidden_state.cpu().numpy()[v] - g["hidden"][v]).max() < 6e-2
+    assert tuple(out.pooler_output.shape) == (3, pcfg.hidden_size)
