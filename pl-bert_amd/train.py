@@ -182,6 +182,8 @@ class AdamW:
         self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.step_count = 0
         self.grad_scale = 1.0
+        by_id = {id(p): n for n, p in model.named_parameters()}
+        self._names = [by_id[id(p)] for p in self.param_list]
 
     def zero_grad(self, set_to_none=True):
         for p in self.param_list:
@@ -192,6 +194,13 @@ class AdamW:
         # zero-loss fallback) changes nothing; otherwise the trainable range is updated in one launch
         if all(p.grad is None for p in self.param_list):
             return
+        e = self.engine
+        for n, p in zip(self._names, self.param_list):
+            # autograd may have handed the Parameter a copy of its gradient slice (or user code replaced
+            # / clipped .grad): whatever .grad holds now is what the fused update must consume
+            off, size, shp = e.layout[n]
+            if p.grad is not None and off + size <= e.trainable and p.grad.data_ptr() != e.grads.data_ptr() + 4 * off:
+                e.grads[off:off + size].view(shp).copy_(p.grad)
         self.step_count += 1
         d = self.defaults
         self.engine.adamw_step(self.step_count, d["lr"], d["betas"], d["eps"], d["weight_decay"], self.grad_scale)
