@@ -154,6 +154,8 @@ def lib():
     # internal launchers (kernel-level tests)
     L.plb_launch_gemm_nt.restype = C.c_int
     L.plb_launch_gemm_nt.argtypes = [C.POINTER(PlbGemmNT), C.c_int, C.c_int, vp]
+    L.plb_set_gemm_nt_tile.restype = None
+    L.plb_set_gemm_nt_tile.argtypes = [C.c_int]
     L.plb_launch_gemm_tn.restype = C.c_int
     L.plb_launch_gemm_tn.argtypes = [C.POINTER(PlbGemmTN), vp]
     L.plb_launch_reduce_slabs.restype = C.c_int

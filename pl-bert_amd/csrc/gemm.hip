@@ -13,6 +13,7 @@
 // the ds_write_b128 staging stores are bank-conflict free.
 #include "common.h"
 #include "plbert_kernels.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -104,39 +105,9 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(PlbGemmNT p) {
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int m = bm * BM + wr * 64 + mi * 16 + frow;
-    if (m >= p.Mstore) continue;
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-      const int n0 = bn * BN + wc * 64 + ni * 16 + fq * 4;
-      if (n0 >= p.N) continue;
-      f32x4 v = acc[mi][ni];
-      if (p.bias) {
-        float4 b = *(const float4*)(p.bias + n0);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      if (p.res) {
-        uint2 r = *(const uint2*)(p.res + (size_t)m * p.ldr + n0);
-        v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
-      }
-      if (ACT == 2) {  // gelu backward: multiply by gelu_new'(u)
-        uint2 u = *(const uint2*)(p.aux + (size_t)m * p.ldaux + n0);
-        v[0] *= gelu_new_grad_f(bf_lo(u.x)); v[1] *= gelu_new_grad_f(bf_hi(u.x));
-        v[2] *= gelu_new_grad_f(bf_lo(u.y)); v[3] *= gelu_new_grad_f(bf_hi(u.y));
-      }
-      if (OUTF32) {
-        *(float4*)(p.Cf + (size_t)m * p.ldcf + n0) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-        *(uint2*)(p.C + (size_t)m * p.ldc + n0) = o;
-        if (ACT == 1) {  // gelu forward: C keeps the pre-activation u (rounded to bf16, as consumed by
-                         // the backward), C2 = gelu_new(u)
-          uint2 g;
-          g.x = pack_bf2(gelu_new_f(bf_lo(o.x)), gelu_new_f(bf_hi(o.x)));
-          g.y = pack_bf2(gelu_new_f(bf_lo(o.y)), gelu_new_f(bf_hi(o.y)));
-          *(uint2*)(p.C2 + (size_t)m * p.ldc2 + n0) = g;
-        }
-      }
-    }
+    for (int ni = 0; ni < 4; ++ni)
+      nt_epilogue<ACT, OUTF32>(p, acc[mi][ni], m, bn * BN + wc * 64 + ni * 16 + fq * 4);
   }
 }
 
@@ -243,11 +214,37 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(PlbGemmTN p) {
 
 }  // namespace
 
+static int g_nt_tile = 0;  // 0: pick per shape; 128 / 256 / 384: force that tile where the shape allows
+extern "C" void plb_set_gemm_nt_tile(int tile) { g_nt_tile = tile; }
+extern "C" int plb_launch_gemm_nt_big(const PlbGemmNT* p, int tile, int act, int out_f32, hipStream_t stream);
+
+// Tile policy: fill 256 CUs. efficiency = tiles / (rounds * 256) with one workgroup per CU for the
+// big tiles; 128x384 moves 4/3 the operand bytes per flop of 256x256, hence the small handicap.
+static int pick_tile(const PlbGemmNT* p) {
+  const bool ok256 = p->M % 256 == 0 && p->N % 256 == 0, ok384 = p->M % 128 == 0 && p->N % 384 == 0;
+  if (g_nt_tile == 128) return 128;
+  if (g_nt_tile == 256) return ok256 ? 256 : 128;
+  if (g_nt_tile == 384) return ok384 ? 384 : (ok256 ? 256 : 128);
+  if ((long)p->M * p->N < 256L * 256 * 64) return 128;  // small problems: more, smaller workgroups
+  double e256 = 0, e384 = 0;
+  if (ok256) { const long t = (long)(p->M / 256) * (p->N / 256); e256 = (double)t / (double)(((t + 255) / 256) * 256); }
+  if (ok384) { const long t = (long)(p->M / 128) * (p->N / 384); e384 = 0.95 * (double)t / (double)(((t + 255) / 256) * 256); }
+  if (e256 == 0 && e384 == 0) return 128;
+  return e384 > e256 ? 384 : 256;
+}
+
 extern "C" int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {
   if (p->M % BM || p->K % BK || p->N % 4 || p->M <= 0 || p->N <= 0 || p->K <= 0) return 1;
   const int nbn = (p->N + BN - 1) / BN;
   dim3 grid((p->M / BM) * nbn), block(256);
   const int cls = out_f32 ? PLB_K_GEMM_NT_F32 : act == 1 ? PLB_K_GEMM_NT_GELU : act == 2 ? PLB_K_GEMM_NT_GELUBWD : PLB_K_GEMM_NT;
+  const int tile = pick_tile(p);
+  if (tile != 128) {
+    const int tokb = plb_prof_begin(cls, stream, 2.0 * (double)p->M * p->N * p->K, 0.0);
+    const int rc = plb_launch_gemm_nt_big(p, tile, act, out_f32, stream);
+    plb_prof_end(tokb, stream);
+    return rc;
+  }
   const double mnk = (double)p->M * p->N * p->K;
   const int tok = plb_prof_begin(cls, stream, 2.0 * mnk,
                                  2.0 * ((double)p->M * p->K + (double)p->N * p->K) +

@@ -1,0 +1,234 @@
+// Large-tile NT GEMMs with a multi-phase, counted-vmcnt LDS-DMA pipeline (gfx950).
+//
+// Why: at a 128x128 tile the operand stream into LDS is 64 FLOP/B — ~9 TB/s of L2->LDS traffic at
+// 600 TFLOP/s, and the kernel is bound by that load path, not by the MFMA pipe. Here one workgroup of
+// 8 waves (2 per SIMD) owns a CU, the tile is 256x256 (128 FLOP/B) or 128x384 (96 FLOP/B), and three
+// 16 KiB half-tiles of LDS-DMA stay in flight across barriers (s_waitcnt vmcnt(6), never 0 in steady
+// state). Tile choice is by wave quantisation on 256 CUs: N = 768 -> 128x384 gives exactly 256 tiles
+// at M = 16384 (256x256 would give 192: a quarter of the chip idle), N = 2304 -> 768 tiles = 3 per CU.
+//
+// A K-tile (64 deep) is four 128-row half-tiles in LDS, slots per buffer:
+//   256x256: A0 A1 B0 B1        128x384: A B0 B1 B2              (2 buffers x 4 x 16 KiB = 128 KiB)
+// 8 waves = 2 (M) x 4 (N). Wave (wm, wn) owns rows {mh*128 + wm*64 + 0..63} and columns
+// {nh*128 + wn*32 + 0..31} of every (mh, nh): its output is interleaved over the half-tiles, so one
+// phase (16 MFMAs 16x16x32 = a 64x32 patch) reads fragments of ONE A half and ONE B half, and the
+// half-tiles of a K-tile are consumed (and their slots freed for the DMA of K-tile t+2) in order:
+//   256x256:  ph1 A0,B0 -> (0,0) | ph2 B1 -> (0,1) | ph3 A1 -> (1,1) | ph4 (1,0), no reads
+//             DMA issue: ph1 A1(t+1) | ph2 A0(t+2) | ph3 B0(t+2) | ph4 B1(t+2), then vmcnt(6)
+//   128x384:  ph1 A,B0 -> nh 0     | ph2 B1 -> nh 1 | ph3 B2 -> nh 2
+//             DMA issue: ph1 B2(t+1) | ph2 A(t+2),B0(t+2) | ph3 B1(t+2), then vmcnt(6)
+// The vmcnt(6) in the last phase leaves exactly the three newest half-tiles (all of K-tile t+2) in
+// flight, so K-tile t+1 has landed. Two raw s_barriers per phase (asm: __syncthreads() would drain
+// vmcnt to 0) and a half-phase stagger between the two waves of each SIMD — see the loop comment.
+#include "common.h"
+#include "plbert_kernels.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int HT = 128 * 64;  // elements per half-tile (16 KiB)
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Retire this wave's LDS reads, then barrier: a DMA issued by another wave after the barrier may
+// overwrite what those reads were fetching. The "memory" clobber keeps ds_read / global_load_lds on
+// their side of the barrier; sched_barrier pins the register-only MFMAs as well.
+#define BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+
+// NBH = number of B half-tiles per K-tile (2: 256x256 tile, 3: 128x384 tile); A halves = 4 - NBH.
+template <int NBH, int ACT, bool OUTF32>
+__global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
+  constexpr int NAH = 4 - NBH;
+  constexpr int TM = NAH * 128, TN = NBH * 128;
+  constexpr int SB = NAH;  // first B slot
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * HT];  // 128 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = uw >> 2, wn = uw & 3;
+  const int nbn = p.N / TN;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bm = logical / nbn, bn = logical % nbn;
+  const int nk = p.K >> 6;
+
+  // ---- staging: each wave DMAs rows [(2w+j)*8, +8) of a half-tile, j = 0,1 (1 KiB per instruction);
+  // the XOR swizzle of the image is applied to the per-lane SOURCE chunk
+  const int drow = lane >> 3;
+  const int ch0 = ((lane & 7) ^ ((lane >> 4) & 7)) * 8;
+  const int ch1 = ((lane & 7) ^ ((4 + (lane >> 4)) & 7)) * 8;
+  const bf16_t* gA0 = p.A + (size_t)(bm * TM + (2 * uw) * 8 + drow) * p.lda + ch0;
+  const bf16_t* gA1 = p.A + (size_t)(bm * TM + (2 * uw + 1) * 8 + drow) * p.lda + ch1;
+  const bf16_t* gB0 = p.B + (size_t)(bn * TN + (2 * uw) * 8 + drow) * p.ldb + ch0;
+  const bf16_t* gB1 = p.B + (size_t)(bn * TN + (2 * uw + 1) * 8 + drow) * p.ldb + ch1;
+  const size_t hA = (size_t)128 * p.lda, hB = (size_t)128 * p.ldb;
+  const int dst0 = (2 * uw) * 8 * 64, dst1 = (2 * uw + 1) * 8 * 64;
+#define STAGE_A(buf, h, kt)                                                                                   \
+  do {                                                                                                        \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (h) * hA + (size_t)(kt) * 64),                            \
+                                     (lptr_t)&smem[((buf) * 4 + (h)) * HT + dst0], 16, 0, 0);                 \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (h) * hA + (size_t)(kt) * 64),                            \
+                                     (lptr_t)&smem[((buf) * 4 + (h)) * HT + dst1], 16, 0, 0);                 \
+  } while (0)
+#define STAGE_B(buf, h, kt)                                                                                   \
+  do {                                                                                                        \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gB0 + (h) * hB + (size_t)(kt) * 64),                            \
+                                     (lptr_t)&smem[((buf) * 4 + SB + (h)) * HT + dst0], 16, 0, 0);            \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gB1 + (h) * hB + (size_t)(kt) * 64),                            \
+                                     (lptr_t)&smem[((buf) * 4 + SB + (h)) * HT + dst1], 16, 0, 0);            \
+  } while (0)
+
+  // ---- fragment reads: row-in-half = wm*64 + mi*16 + frow (A) / wn*32 + ni*16 + frow (B);
+  // stored chunk = (kk*4 + fq) ^ ((frow>>1)&7)
+  const int frow = lane & 15, fq = lane >> 4, fsw = (frow >> 1) & 7;
+  const int offA = (wm * 64 + frow) * 64, offB = (wn * 32 + frow) * 64;
+  const int c0 = ((0 + fq) ^ fsw) << 3, c1 = ((4 + fq) ^ fsw) << 3;
+  bf16x8 af[4][2], b0f[2][2], b1f[2][2];
+#define READ_A(buf, h)                                                               \
+  do {                                                                               \
+    const bf16_t* s_ = &smem[((buf) * 4 + (h)) * HT + offA];                         \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                               \
+      af[mi][0] = *(const bf16x8*)&s_[mi * 16 * 64 + c0];                            \
+      af[mi][1] = *(const bf16x8*)&s_[mi * 16 * 64 + c1];                            \
+    }                                                                                \
+  } while (0)
+#define READ_B(dst, buf, h)                                                          \
+  do {                                                                               \
+    const bf16_t* s_ = &smem[((buf) * 4 + SB + (h)) * HT + offB];                    \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                               \
+      dst[ni][0] = *(const bf16x8*)&s_[ni * 16 * 64 + c0];                           \
+      dst[ni][1] = *(const bf16x8*)&s_[ni * 16 * 64 + c1];                           \
+    }                                                                                \
+  } while (0)
+
+  f32x4 acc[NAH][4][NBH][2];  // [mh][mi][nh][ni]
+#pragma unroll
+  for (int a = 0; a < NAH; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < NBH; ++c)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // swapped MFMA operands: D[row = n][col = m] -> each lane owns 4 consecutive n of one row m
+#define MFMA_Q(mh, nh, bf)                                                                                     \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                         \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
+          acc[mh][mi][nh][ni] =                                                                                \
+              __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[ni][kk], af[mi][kk], acc[mh][mi][nh][ni], 0, 0, 0);   \
+  } while (0)
+#define MFMA_PART(mh, nh, bf)            \
+  do {                                   \
+    BARRIER(); PIN();                    \
+    __builtin_amdgcn_s_setprio(1);       \
+    MFMA_Q(mh, nh, bf);                  \
+    __builtin_amdgcn_s_setprio(0);       \
+    PIN(); BARRIER(); PIN();             \
+  } while (0)
+#define LANDED(more)                                                      \
+  do {                                                                    \
+    if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+  } while (0)
+
+  // ---- prologue: K-tile 0 complete + the first three half-tiles (in consumption order) of K-tile 1
+  if constexpr (NBH == 2) {
+    STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, NAH - 1, 0);
+    if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
+  } else {
+    STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_B(0, NBH - 1, 0);
+    if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
+  }
+  LANDED(nk > 1);
+  BARRIER();
+  // Stagger: the second wave of every SIMD (waves 4-7 = wm 1) runs half a phase behind the first, so
+  // one group's LDS reads overlap the other group's MFMAs. A phase is {DMA issue, fragment reads,
+  // BARRIER, 16 MFMAs, BARRIER}; the late group executes one extra barrier here and the early group
+  // one after the loop. Consequences for the hand-offs (both checked against the half-phase skew):
+  //  - a vmcnt wait sits BEFORE the first barrier of the last phase and the data is first read in the
+  //    next phase 1: two barriers later for the early group, so the late group's wait has happened;
+  //  - BARRIER() retires the wave's own LDS reads (lgkmcnt(0)) first, so a slot read in phase P by the
+  //    late group is safe to re-fill by the early group's DMA in phase P+1.
+  if (wm == 1) BARRIER();
+
+  for (int t = 0; t < nk; ++t) {
+    const int b = t & 1;
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    if constexpr (NBH == 2) {
+      if (n1) STAGE_A(b ^ 1, NAH - 1, t + 1);
+      READ_B(b0f, b, 0);
+      READ_A(b, 0);
+      MFMA_PART(0, 0, b0f);
+      if (n2) STAGE_A(b, 0, t + 2);
+      READ_B(b1f, b, 1);
+      MFMA_PART(0, 1, b1f);
+      if (n2) STAGE_B(b, 0, t + 2);
+      READ_A(b, NAH - 1);
+      MFMA_PART(NAH - 1, 1, b1f);
+      if (n2) STAGE_B(b, 1, t + 2);
+      LANDED(n2);
+      MFMA_PART(NAH - 1, 0, b0f);
+    } else {
+      if (n1) STAGE_B(b ^ 1, NBH - 1, t + 1);
+      READ_B(b0f, b, 0);
+      READ_A(b, 0);
+      MFMA_PART(0, 0, b0f);
+      if (n2) { STAGE_A(b, 0, t + 2); STAGE_B(b, 0, t + 2); }
+      READ_B(b1f, b, 1);
+      MFMA_PART(0, 1, b1f);
+      if (n2) STAGE_B(b, 1, t + 2);
+      LANDED(n2);
+      READ_B(b0f, b, NBH - 1);
+      MFMA_PART(0, NBH - 1, b0f);
+    }
+  }
+  if (wm == 0) BARRIER();
+#undef STAGE_A
+#undef STAGE_B
+#undef READ_A
+#undef READ_B
+#undef MFMA_Q
+#undef MFMA_PART
+#undef LANDED
+
+#pragma unroll
+  for (int mh = 0; mh < NAH; ++mh)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = bm * TM + mh * 128 + wm * 64 + mi * 16 + frow;
+#pragma unroll
+      for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          nt_epilogue<ACT, OUTF32>(p, acc[mh][mi][nh][ni], m, bn * TN + nh * 128 + wn * 32 + ni * 16 + fq * 4);
+    }
+}
+
+template <int NBH>
+int launch_big(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {
+  constexpr int TM = (4 - NBH) * 128, TN = NBH * 128;
+  if (p->M % TM || p->N % TN || p->K % 64 || p->M <= 0 || p->N <= 0 || p->K <= 0) return 1;
+  dim3 grid((p->M / TM) * (p->N / TN)), block(512);
+  if (out_f32) {
+    if (act != 0) return 1;
+    hipLaunchKernelGGL((gemm_nt_big_kernel<NBH, 0, true>), grid, block, 0, stream, *p);
+  } else if (act == 0) {
+    hipLaunchKernelGGL((gemm_nt_big_kernel<NBH, 0, false>), grid, block, 0, stream, *p);
+  } else if (act == 1) {
+    hipLaunchKernelGGL((gemm_nt_big_kernel<NBH, 1, false>), grid, block, 0, stream, *p);
+  } else if (act == 2) {
+    hipLaunchKernelGGL((gemm_nt_big_kernel<NBH, 2, false>), grid, block, 0, stream, *p);
+  } else {
+    return 1;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+
+}  // namespace
+
+// tile = 256: 256x256 (M % 256, N % 256); tile = 384: 128x384 (M % 128, N % 384). K % 64 == 0.
+extern "C" int plb_launch_gemm_nt_big(const PlbGemmNT* p, int tile, int act, int out_f32, hipStream_t stream) {
+  return tile == 384 ? launch_big<3>(p, act, out_f32, stream) : launch_big<2>(p, act, out_f32, stream);
+}

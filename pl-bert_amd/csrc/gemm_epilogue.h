@@ -1,0 +1,37 @@
+// Shared epilogue of the NT GEMM kernels: one lane holds 4 consecutive output columns of one row.
+#pragma once
+#include "common.h"
+#include "plbert_kernels.h"
+
+// v = acc (+bias) (+residual) (*gelu_new'(aux) when ACT == 2) -> bf16 C (and C2 = gelu_new(C) when
+// ACT == 1) or fp32 Cf. Rows >= Mstore and columns >= N are not stored.
+template <int ACT, bool OUTF32>
+DEVI void nt_epilogue(const PlbGemmNT& p, f32x4 v, int m, int n0) {
+  if (m >= p.Mstore || n0 >= p.N) return;
+  if (p.bias) {
+    float4 b = *(const float4*)(p.bias + n0);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (p.res) {
+    uint2 r = *(const uint2*)(p.res + (size_t)m * p.ldr + n0);
+    v[0] += bf_lo(r.x); v[1] += bf_hi(r.x); v[2] += bf_lo(r.y); v[3] += bf_hi(r.y);
+  }
+  if (ACT == 2) {  // gelu backward: multiply by gelu_new'(u)
+    uint2 u = *(const uint2*)(p.aux + (size_t)m * p.ldaux + n0);
+    v[0] *= gelu_new_grad_f(bf_lo(u.x)); v[1] *= gelu_new_grad_f(bf_hi(u.x));
+    v[2] *= gelu_new_grad_f(bf_lo(u.y)); v[3] *= gelu_new_grad_f(bf_hi(u.y));
+  }
+  if (OUTF32) {
+    *(float4*)(p.Cf + (size_t)m * p.ldcf + n0) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+    uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+    *(uint2*)(p.C + (size_t)m * p.ldc + n0) = o;
+    if (ACT == 1) {  // gelu forward: C keeps the pre-activation u (rounded to bf16, as consumed by the
+                     // backward), C2 = gelu_new(u)
+      uint2 g;
+      g.x = pack_bf2(gelu_new_f(bf_lo(o.x)), gelu_new_f(bf_hi(o.x)));
+      g.y = pack_bf2(gelu_new_f(bf_lo(o.y)), gelu_new_f(bf_hi(o.y)));
+      *(uint2*)(p.C2 + (size_t)m * p.ldc2 + n0) = g;
+    }
+  }
+}

@@ -38,6 +38,28 @@ def test_gemm_nt_bias_residual(M, N, K):
     assert (outf[M - 5:] == 0).all()  # rows past Mstore untouched
 
 
+@pytest.mark.parametrize("tile,M,N,K", [(256, 256, 256, 64), (256, 512, 768, 768), (256, 256, 512, 128), (256, 512, 256, 192),
+                                        (384, 128, 384, 64), (384, 384, 768, 768), (384, 256, 2304, 128), (384, 128, 384, 2048)])
+def test_gemm_nt_big_tiles(tile, M, N, K):
+    """256x256 / 128x384 multi-phase kernels: 1, 2, 3 and many K-tiles (prologue, steady state, drain)."""
+    L = _lib.lib()
+    A, Bw = randbf(M, K, seed=21), randbf(N, K, scale=0.05, seed=22)
+    bias = torch.randn(N, device=DEV)
+    res = randbf(M, N, seed=23)
+    ref = A.float() @ Bw.float().T + bias + res.float()
+    try:
+        L.plb_set_gemm_nt_tile(tile)
+        out, _ = gemm_nt(A, Bw, N, bias=bias, res=res)
+        outf, _ = gemm_nt(A, Bw, N, bias=bias, out_f32=True)
+        u, g = gemm_nt(A, Bw, N, bias=bias, act=1)
+    finally:
+        L.plb_set_gemm_nt_tile(0)
+    assert rel_l2(out.float(), ref) < 4e-3
+    assert (out.float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-3
+    assert rel_l2(outf, A.float() @ Bw.float().T + bias) < 1e-5
+    assert rel_l2(g.float(), gelu_new(u.float())) < 5e-3
+
+
 def test_gemm_nt_gelu_epilogues():
     M, N, K = 256, 256, 128
     A, Bw = randbf(M, K, seed=4), randbf(N, K, scale=0.2, seed=5)
