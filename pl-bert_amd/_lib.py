@@ -158,6 +158,8 @@ def lib():
     L.plb_set_gemm_nt_tile.argtypes = [C.c_int]
     L.plb_launch_gemm_tn.restype = C.c_int
     L.plb_launch_gemm_tn.argtypes = [C.POINTER(PlbGemmTN), vp]
+    L.plb_launch_gemm_tn_big.restype = C.c_int
+    L.plb_launch_gemm_tn_big.argtypes = [C.POINTER(PlbGemmTN), vp]
     L.plb_launch_reduce_slabs.restype = C.c_int
     L.plb_launch_reduce_slabs.argtypes = [vp, C.c_int, C.c_size_t, vp, C.c_int, vp]
     L.plb_launch_attn_fwd.restype = C.c_int

@@ -146,9 +146,18 @@ static void layout_params(PlbEngine* e) {
   e->ptotal = off;
 }
 
+// Row splits of a token-major weight-gradient GEMM. Shapes that fit the 256x256 pipeline kernel get
+// one workgroup per CU (tiles x splits <= 256); the rest use the 128x128 kernel at ~3 workgroups per CU.
+static bool tn_big(int64_t Mtot, int Ncols, int K) { return Ncols % 256 == 0 && K % 256 == 0 && Mtot >= 8192; }
 static int tn_splits(int64_t Mtot, int N, int K, int* rows_per_split) {
-  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  const bool big = tn_big(Mtot, N, K);
+  const int tiles = big ? (N / 256) * (K / 256) : ((N + 127) / 128) * ((K + 127) / 128);
   int splits = 768 / tiles;
+  if (big) {  // one split group per XCD: 8 * s splits with s * tiles <= 32 CUs of an XCD
+    int s = 32 / tiles;
+    if (s < 1) s = 1;
+    splits = 8 * s;
+  }
   const int64_t maxs = Mtot / 64;
   if (splits > maxs) splits = (int)maxs;
   if (splits < 1) splits = 1;
@@ -181,7 +190,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   const int64_t Tp = rup(T, 128);
   e->Tcap = Tp;
   e->NMcap = Tp;
-  e->ln_blocks = 1024;
+  e->ln_blocks = 512;
   e->emb_blocks = 256;
   Carve cv;
   // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes
@@ -237,8 +246,8 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   }
   e->slab_floats = slab;
   e->o_slab = cv.take(slab * 4);
-  e->o_part1 = cv.take(L * e->ln_blocks * 2 * H * 4);
-  e->o_part2 = cv.take(L * e->ln_blocks * 2 * H * 4);
+  e->o_part1 = cv.take(L * e->ln_blocks * 3 * H * 4);  // per LN-backward block: dgamma | dbeta | colsum(dx)
+  e->o_part2 = cv.take(L * e->ln_blocks * 3 * H * 4);
   e->o_parte = cv.take((int64_t)e->emb_blocks * 2 * E * 4);
   e->o_scratch = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);  // colsum partials: up to 512 row splits
   e->ws_bytes = cv.off;
@@ -419,7 +428,13 @@ static int weight_grad(PlbEngine* e, const bf16_t* A, int lda, int Ncols, const 
   t.splits = tn_splits(Mtot, N, K, &t.rows_per_split);
   if ((int64_t)t.splits * N * K > e->slab_floats) return fail("weight_grad: slab too small");
   t.slab = e->at<float>(e->o_slab);
-  TRY(plb_launch_gemm_tn(&t, s));
+  if (N == Ncols && tn_big(Mtot, Ncols, K)) {
+    const int tok = plb_prof_begin(PLB_K_GEMM_TN, s, 2.0 * (double)Mtot * N * K, 0.0);
+    TRY(plb_launch_gemm_tn_big(&t, s));
+    plb_prof_end(tok, s);
+  } else {
+    TRY(plb_launch_gemm_tn(&t, s));
+  }
   TRY(plb_launch_reduce_slabs(t.slab, t.splits, (size_t)N * K, out, 0, s));
   return 0;
 }
@@ -493,7 +508,7 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
     ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
     ln.mean = e->at<float>(e->o_mean2) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd2) + (int64_t)l * Tp;
     ln.dy = dy; ln.lddy = H; ln.dx = dpre2; ln.lddx = H;
-    ln.partials = e->at<float>(e->o_part2) + (int64_t)l * e->ln_blocks * 2 * H; ln.nblocks = e->ln_blocks;
+    ln.partials = e->at<float>(e->o_part2) + (int64_t)l * e->ln_blocks * 3 * H; ln.nblocks = e->ln_blocks;
     TRY(plb_launch_ln_bwd(&ln, s));
     // dU = (dpre2 · W2) ∘ gelu'(u)
     memset(&g, 0, sizeof(g));
@@ -509,7 +524,7 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
     ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
     ln.mean = e->at<float>(e->o_mean1) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd1) + (int64_t)l * Tp;
     ln.dy = da; ln.lddy = H; ln.dx = dpre1; ln.lddx = H;
-    ln.partials = e->at<float>(e->o_part1) + (int64_t)l * e->ln_blocks * 2 * H; ln.nblocks = e->ln_blocks;
+    ln.partials = e->at<float>(e->o_part1) + (int64_t)l * e->ln_blocks * 3 * H; ln.nblocks = e->ln_blocks;
     TRY(plb_launch_ln_bwd(&ln, s));
     // dCtx = dpre1 · Wd
     memset(&g, 0, sizeof(g));
@@ -560,11 +575,14 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   if (weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
   TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dqkv), 1, (size_t)Mtot, 3 * H, 3 * H, e->grd(PLB_Q_B), 3 * H, 0, scratch, 128, s));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre1), 1, (size_t)Mtot, H, H, e->grd(PLB_DENSE_B), H, 0, scratch, 384, s));
   TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 128, s));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre2), 1, (size_t)Mtot, H, H, e->grd(PLB_FFNO_B), H, 0, scratch, 384, s));
-  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, (size_t)L * e->ln_blocks, 2 * H, 2 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch, 16, s));
-  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, (size_t)L * e->ln_blocks, 2 * H, 2 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch, 16, s));
+  // LayerNorm-backward partials [L*blocks][3H]: dgamma|dbeta -> the LN parameters, colsum(dx) -> the bias
+  // of the Linear whose output (+residual) the LN normalises (dense for LN1, ffn_output for LN2)
+  const size_t prow = (size_t)L * e->ln_blocks;
+  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 2 * H, 3 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch, 16, s));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part1) + 2 * H, 0, prow, H, 3 * H, e->grd(PLB_DENSE_B), H, 0, scratch, 16, s));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 2 * H, 3 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch, 16, s));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part2) + 2 * H, 0, prow, H, 3 * H, e->grd(PLB_FFNO_B), H, 0, scratch, 16, s));
   return 0;
 }
 

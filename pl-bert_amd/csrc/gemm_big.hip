@@ -226,7 +226,200 @@ int launch_big(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// dW[N,K] = A[rows,N]^T · B[rows,K]: the token-major ("TN") weight-gradient GEMM on the same pipeline.
+// Output tile 256 (n) x 256 (k); the reduction runs over token rows t in steps of 64 and is split over
+// blockIdx.y into fp32 slabs. A half-tile is [64 t][128 cols] = two [64][64] LDS images with 128-B
+// rows filled by LDS-DMA in full 128-B lines. MFMA fragments need the reduction index on the k
+// axis, i.e. COLUMNS of these images: ds_read_b64_tr_b16. A half-wave's transposed read touches rows
+// {r..r+3, r+8..r+11} x 32 B; XOR-ing the 32-B pair index with ((row>>1)&1) | ((row>>3)&1)<<1 spreads
+// those eight segments over all 64 banks (the swizzle is applied to the DMA's per-lane source chunk).
+DEVI int tn_g(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
+
+__global__ __launch_bounds__(512) void gemm_tn_big_kernel(PlbGemmTN p) {
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * HT];  // [buf][A0,A1,B0,B1][2 images][64][64]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = uw >> 2, wn = uw & 3;
+  // Work placement: every tile of one row split streams the same token rows, so the tiles of a split
+  // should share an L2. Blocks are dealt round-robin over the 8 XCDs (block id % 8 labels the XCD
+  // group — speed only, never correctness): XCD x takes splits [x*s, (x+1)*s), all their tiles.
+  const int nbk = p.K >> 8;
+  const int tiles = (p.Ncols >> 8) * nbk;
+  int split, tile;
+  if ((p.splits & 7) == 0) {
+    const int spx = p.splits >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    split = xcd * spx + slot / tiles;
+    tile = slot % tiles;
+  } else {
+    split = blockIdx.x / tiles;
+    tile = blockIdx.x % tiles;
+  }
+  const int bn = tile / nbk, bk = tile % nbk;
+  const int t_begin = split * p.rows_per_split;
+  int t_end = t_begin + p.rows_per_split;
+  if (t_end > p.Mtot) t_end = p.Mtot;
+  const int nk = (t_end - t_begin) >> 6;
+
+  // ---- staging: instruction i = 2w + j of a half-tile covers image i>>3, rows (i&7)*8 + (lane>>3)
+  const int i0 = 2 * uw, i1 = 2 * uw + 1;
+  const int r0 = (i0 & 7) * 8 + (lane >> 3), r1 = (i1 & 7) * 8 + (lane >> 3);
+  const int sc0 = (((lane & 7) ^ (2 * tn_g(r0))) * 8) + (i0 >> 3) * 64;  // source column within the half
+  const int sc1 = (((lane & 7) ^ (2 * tn_g(r1))) * 8) + (i1 >> 3) * 64;
+  const bf16_t* gA0 = p.A + (size_t)(t_begin + r0) * p.lda + bn * 256 + sc0;
+  const bf16_t* gA1 = p.A + (size_t)(t_begin + r1) * p.lda + bn * 256 + sc1;
+  const bf16_t* gB0 = p.B + (size_t)(t_begin + r0) * p.ldb + bk * 256 + sc0;
+  const bf16_t* gB1 = p.B + (size_t)(t_begin + r1) * p.ldb + bk * 256 + sc1;
+  const size_t tA = (size_t)64 * p.lda, tB = (size_t)64 * p.ldb;
+  const int dst0 = (i0 >> 3) * 4096 + (i0 & 7) * 8 * 64, dst1 = (i1 >> 3) * 4096 + (i1 & 7) * 8 * 64;
+#define STAGE_A(buf, h, kt)                                                                                   \
+  do {                                                                                                        \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (h) * 128 + (size_t)(kt) * tA),                           \
+                                     (lptr_t)&smem[((buf) * 4 + (h)) * HT + dst0], 16, 0, 0);                 \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (h) * 128 + (size_t)(kt) * tA),                           \
+                                     (lptr_t)&smem[((buf) * 4 + (h)) * HT + dst1], 16, 0, 0);                 \
+  } while (0)
+#define STAGE_B(buf, h, kt)                                                                                   \
+  do {                                                                                                        \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gB0 + (h) * 128 + (size_t)(kt) * tB),                           \
+                                     (lptr_t)&smem[((buf) * 4 + 2 + (h)) * HT + dst0], 16, 0, 0);             \
+    __builtin_amdgcn_global_load_lds((gptr_t)(gB1 + (h) * 128 + (size_t)(kt) * tB),                           \
+                                     (lptr_t)&smem[((buf) * 4 + 2 + (h)) * HT + dst1], 16, 0, 0);             \
+  } while (0)
+
+  // ---- fragment reads (transposed): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3;
+  // k-step kk covers t rows kk*32 + 8*(lane>>4) + {0..3} (first read) and +4 (second read)
+  const int fg = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+  // A fragment (mi): image wm of the half, columns mi*16 + 4p ; B fragment (ni): image wn>>1, columns
+  // (wn&1)*32 + ni*16 + 4p. The swizzle term of row kk*32 + 8*fg + 4*s2 + q depends on the lane only
+  // (((row>>1)&1) = (q>>1)&1, ((row>>3)&1) = fg&1), so every read is lane base + compile-time offset.
+  const int gsw = 2 * (((q4 >> 1) & 1) | ((fg & 1) << 1));
+  const int rowbase = (8 * fg + q4) * 64 + (p4 & 1) * 4;
+  int aoff[4], boff[2];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) aoff[mi] = wm * 4096 + rowbase + (((2 * mi + (p4 >> 1)) ^ gsw) << 3);
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni)
+    boff[ni] = (wn >> 1) * 4096 + rowbase + (((4 * (wn & 1) + 2 * ni + (p4 >> 1)) ^ gsw) << 3);
+  // The transposed reads are inline asm: through the builtin, hipcc cannot prove that a read does not
+  // alias an in-flight LDS-DMA and drains vmcnt to 0 before every phase's reads. The asm reads are
+  // invisible to its waitcnt pass; BARRIER() (lgkmcnt(0) + s_barrier, followed by a sched_barrier)
+  // retires them before any MFMA consumes a fragment, and fragments are only assembled after it.
+  const unsigned lds0 = (unsigned)(size_t)&smem[0];
+  s16x4 ra[4][4], rb0[2][4], rb1[2][4];  // raw halves: [frag][kk*2 + second]
+#define TR4(dst, addr)                                                                                   \
+  asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"                  \
+               "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"           \
+               : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(addr) : "memory")
+#define READ_A(buf, h)                                                                                   \
+  do {                                                                                                   \
+    const unsigned sb_ = lds0 + 2u * (((buf) * 4 + (h)) * HT);                                           \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) TR4(ra[mi], sb_ + 2u * aoff[mi]);                   \
+  } while (0)
+#define READ_B(dst, buf, h)                                                                              \
+  do {                                                                                                   \
+    const unsigned sb_ = lds0 + 2u * (((buf) * 4 + 2 + (h)) * HT);                                       \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) TR4(dst[ni], sb_ + 2u * boff[ni]);                  \
+  } while (0)
+#define FRAG(r, kk) (bf16x8{r[2 * (kk)][0], r[2 * (kk)][1], r[2 * (kk)][2], r[2 * (kk)][3],              \
+                            r[2 * (kk) + 1][0], r[2 * (kk) + 1][1], r[2 * (kk) + 1][2], r[2 * (kk) + 1][3]})
+
+  f32x4 acc[2][4][2][2];  // [mh][mi][nh][ni]: n = mh*128 + wm*64 + mi*16 + .., k = nh*128 + wn*32 + ni*16 + ..
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define MFMA_Q(mh, nh, rb)                                                                                     \
+  do {                                                                                                         \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                         \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
+          acc[mh][mi][nh][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FRAG(rb[ni], kk), FRAG(ra[mi], kk),    \
+                                                                        acc[mh][mi][nh][ni], 0, 0, 0);         \
+  } while (0)
+#define MFMA_PART(mh, nh, bf)            \
+  do {                                   \
+    BARRIER(); PIN();                    \
+    __builtin_amdgcn_s_setprio(1);       \
+    MFMA_Q(mh, nh, bf);                  \
+    __builtin_amdgcn_s_setprio(0);       \
+    PIN(); BARRIER(); PIN();             \
+  } while (0)
+#define LANDED(more)                                                      \
+  do {                                                                    \
+    if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+  } while (0)
+
+  if (nk > 0) {
+    STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, 1, 0);
+    if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
+    LANDED(nk > 1);
+  }
+  BARRIER();
+  if (wm == 1) BARRIER();  // half-phase stagger, as in gemm_nt_big_kernel
+  for (int t = 0; t < nk; ++t) {
+    const int b = t & 1;
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+    if (n1) STAGE_A(b ^ 1, 1, t + 1);
+    READ_B(rb0, b, 0);
+    READ_A(b, 0);
+    MFMA_PART(0, 0, rb0);
+    if (n2) STAGE_A(b, 0, t + 2);
+    READ_B(rb1, b, 1);
+    MFMA_PART(0, 1, rb1);
+    if (n2) STAGE_B(b, 0, t + 2);
+    READ_A(b, 1);
+    MFMA_PART(1, 1, rb1);
+    if (n2) STAGE_B(b, 1, t + 2);
+    LANDED(n2);
+    MFMA_PART(1, 0, rb0);
+  }
+  if (wm == 0) BARRIER();
+#undef STAGE_A
+#undef STAGE_B
+#undef TR4
+#undef FRAG
+#undef READ_A
+#undef READ_B
+#undef MFMA_Q
+#undef MFMA_PART
+#undef LANDED
+
+  // D[row = k][col = n] (B fragment first): lane owns dW[n = .. + li][k0 .. k0+3]
+  float* out = p.slab + (size_t)split * p.N * p.K;
+#pragma unroll
+  for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int n = bn * 256 + mh * 128 + wm * 64 + mi * 16 + li;
+      if (n >= p.N) continue;
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int k0 = bk * 256 + nh * 128 + wn * 32 + ni * 16 + 4 * fg;
+          const f32x4 v = acc[mh][mi][nh][ni];
+          *(float4*)(out + (size_t)n * p.K + k0) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 }  // namespace
+
+// Token-major weight gradient on the big-tile pipeline: Ncols % 256 == 0 (readable columns of A), K % 256
+// == 0, rows_per_split % 64 == 0. N (rows stored) may be smaller than Ncols.
+extern "C" int plb_launch_gemm_tn_big(const PlbGemmTN* p, hipStream_t stream) {
+  if (p->Ncols % 256 || p->K % 256 || p->rows_per_split % 64 || p->Mtot % 64 || p->splits <= 0) return 1;
+  if ((long)p->splits * p->rows_per_split < p->Mtot) return 1;
+  dim3 grid((p->Ncols / 256) * (p->K / 256) * p->splits), block(512);
+  hipLaunchKernelGGL(gemm_tn_big_kernel, grid, block, 0, stream, *p);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 
 // tile = 256: 256x256 (M % 256, N % 256); tile = 384: 128x384 (M % 128, N % 384). K % 64 == 0.
 extern "C" int plb_launch_gemm_nt_big(const PlbGemmNT* p, int tile, int act, int out_f32, hipStream_t stream) {

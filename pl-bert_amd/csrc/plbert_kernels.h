@@ -42,6 +42,8 @@ typedef struct {
   float* slab;
 } PlbGemmTN;
 int plb_launch_gemm_tn(const PlbGemmTN* p, hipStream_t stream);
+// 256x256-tile pipeline version: Ncols % 256 == 0, K % 256 == 0 (gemm_big.hip)
+int plb_launch_gemm_tn_big(const PlbGemmTN* p, hipStream_t stream);
 
 // out[n] (+)= sum over splits of slab[s][n]   (n = count of floats)
 int plb_launch_reduce_slabs(const float* slab, int splits, size_t n, float* out, int accumulate, hipStream_t stream);
@@ -69,7 +71,7 @@ typedef struct {
   float *mean, *rstd;           // [T]
   int T, H;
   int Tzero;                    // backward: rows T..Tzero-1 of dx are written as zeros
-  // backward: dx = LN'(dy); partials[nblocks][2H] = dgamma | dbeta
+  // backward: dx = LN'(dy); partials[nblocks][3H] = dgamma | dbeta | column sums of dx
   const bf16_t* dy; int lddy;
   bf16_t* dx; int lddx;
   float* partials; int nblocks;

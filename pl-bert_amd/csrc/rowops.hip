@@ -138,18 +138,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(PlbLayerNorm p) {
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
-  __shared__ float red[4][2][1024];
+  __shared__ float red[4][3][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = p.H;
   const float invH = 1.0f / (float)H;
-  float dg[NCH][4], db[NCH][4], gm[NCH][4];
+  float dg[NCH][4], db[NCH][4], gm[NCH][4], ds[NCH][4];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = (lane + 64 * i) * 4;
     float4 g = (c < H) ? *(const float4*)(p.gamma + c) : make_float4(0, 0, 0, 0);
     gm[i][0] = g.x; gm[i][1] = g.y; gm[i][2] = g.z; gm[i][3] = g.w;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = ds[i][j] = 0.f;
   }
   for (int t = blockIdx.x * 4 + wave; t < p.T; t += gridDim.x * 4) {
     const float mean = p.mean[t], rstd = p.rstd[t];
@@ -182,6 +182,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
         o.x = pack_bf2(rstd * (dxh[i][0] - s1 - xh[i][0] * s2), rstd * (dxh[i][1] - s1 - xh[i][1] * s2));
         o.y = pack_bf2(rstd * (dxh[i][2] - s1 - xh[i][2] * s2), rstd * (dxh[i][3] - s1 - xh[i][3] * s2));
         *(uint2*)(p.dx + (size_t)t * p.lddx + c) = o;
+        // column sums of the ROUNDED dx: exactly what a column sum over the stored bf16 tensor gives
+        ds[i][0] += bf_lo(o.x); ds[i][1] += bf_hi(o.x); ds[i][2] += bf_lo(o.y); ds[i][3] += bf_hi(o.y);
       }
     }
   }
@@ -198,13 +200,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { red[wave][0][c + j] = dg[i][j]; red[wave][1][c + j] = db[i][j]; }
+      for (int j = 0; j < 4; ++j) {
+        red[wave][0][c + j] = dg[i][j]; red[wave][1][c + j] = db[i][j]; red[wave][2][c + j] = ds[i][j];
+      }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * H; i += 256) {
+  for (int i = threadIdx.x; i < 3 * H; i += 256) {
     const int which = i / H, col = i % H;
-    p.partials[(size_t)blockIdx.x * 2 * H + i] =
+    p.partials[(size_t)blockIdx.x * 3 * H + i] =
         red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
   }
 }
@@ -223,7 +227,23 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* X, size_t R, in
   size_t r1 = r0 + rows_per; if (r1 > R) r1 = R;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < N) {
-    for (size_t r = r0 + rsub; r < r1; r += 8) {
+    size_t r = r0 + rsub;
+    if (BF16) {  // 4 independent 16-B loads in flight per thread (the sums are latency-bound otherwise)
+      const bf16_t* px = (const bf16_t*)X + c;
+      for (; r + 24 < r1; r += 32) {
+        uint4 u0 = *(const uint4*)(px + r * ld), u1 = *(const uint4*)(px + (r + 8) * ld);
+        uint4 u2 = *(const uint4*)(px + (r + 16) * ld), u3 = *(const uint4*)(px + (r + 24) * ld);
+        acc[0] += (bf_lo(u0.x) + bf_lo(u1.x)) + (bf_lo(u2.x) + bf_lo(u3.x));
+        acc[1] += (bf_hi(u0.x) + bf_hi(u1.x)) + (bf_hi(u2.x) + bf_hi(u3.x));
+        acc[2] += (bf_lo(u0.y) + bf_lo(u1.y)) + (bf_lo(u2.y) + bf_lo(u3.y));
+        acc[3] += (bf_hi(u0.y) + bf_hi(u1.y)) + (bf_hi(u2.y) + bf_hi(u3.y));
+        acc[4] += (bf_lo(u0.z) + bf_lo(u1.z)) + (bf_lo(u2.z) + bf_lo(u3.z));
+        acc[5] += (bf_hi(u0.z) + bf_hi(u1.z)) + (bf_hi(u2.z) + bf_hi(u3.z));
+        acc[6] += (bf_lo(u0.w) + bf_lo(u1.w)) + (bf_lo(u2.w) + bf_lo(u3.w));
+        acc[7] += (bf_hi(u0.w) + bf_hi(u1.w)) + (bf_hi(u2.w) + bf_hi(u3.w));
+      }
+    }
+    for (; r < r1; r += 8) {
       if (BF16) {
         uint4 u = *(const uint4*)((const bf16_t*)X + r * ld + c);
         acc[0] += bf_lo(u.x); acc[1] += bf_hi(u.x); acc[2] += bf_lo(u.y); acc[3] += bf_hi(u.y);

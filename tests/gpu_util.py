@@ -45,7 +45,7 @@ def gemm_nt(A, B, N, bias=None, res=None, aux=None, act=0, out_f32=False, Mstore
     return (Cf if out_f32 else Cb), C2
 
 
-def gemm_tn(A, B, N, splits, rows_per_split):
+def gemm_tn(A, B, N, splits, rows_per_split, big=False):
     """A [Mtot, Ncols] bf16, B [Mtot, K] bf16 -> dW [N,K] fp32 (slabs reduced)."""
     L = _lib.lib()
     Mtot, Ncols = A.shape
@@ -55,7 +55,7 @@ def gemm_tn(A, B, N, splits, rows_per_split):
     p = _lib.PlbGemmTN()
     p.A, p.lda, p.Ncols, p.B, p.ldb = A.data_ptr(), A.stride(0), Ncols, B.data_ptr(), B.stride(0)
     p.Mtot, p.N, p.K, p.rows_per_split, p.splits, p.slab = Mtot, N, K, rows_per_split, splits, slab.data_ptr()
-    rc = L.plb_launch_gemm_tn(C.byref(p), stream())
+    rc = (L.plb_launch_gemm_tn_big if big else L.plb_launch_gemm_tn)(C.byref(p), stream())
     assert rc == 0, rc
     rc = L.plb_launch_reduce_slabs(slab.data_ptr(), splits, N * K, out.data_ptr(), 0, stream())
     assert rc == 0, rc

@@ -40,12 +40,50 @@ def time_nt(L, M, N, K, act, iters=20):
     return ms, 2.0 * M * N * K / (ms * 1e-3) / 1e12
 
 
+TN_SHAPES = [(196608, 2304, 768), (196608, 768, 768), (196608, 2048, 768), (196608, 768, 2048),
+             (16384, 2304, 768), (16384, 768, 768), (32768, 2304, 768)]
+
+
+def time_tn(L, Mtot, N, K, big, iters=5):
+    dev = "cuda"
+    A = torch.randn(Mtot, N, device=dev).to(torch.bfloat16)
+    B = torch.randn(Mtot, K, device=dev).to(torch.bfloat16)
+    tiles = (N // 256) * (K // 256) if big else ((N + 127) // 128) * ((K + 127) // 128)
+    splits = 8 * max(1, 32 // tiles) if big else max(1, 768 // tiles)
+    rps = ((Mtot + splits - 1) // splits + 63) // 64 * 64
+    splits = (Mtot + rps - 1) // rps
+    slab = torch.empty(splits * N * K, dtype=torch.float32, device=dev)
+    p = _lib.PlbGemmTN()
+    p.A, p.lda, p.Ncols, p.B, p.ldb = A.data_ptr(), N, N, B.data_ptr(), K
+    p.Mtot, p.N, p.K, p.rows_per_split, p.splits, p.slab = Mtot, N, K, rps, splits, slab.data_ptr()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fn = L.plb_launch_gemm_tn_big if big else L.plb_launch_gemm_tn
+    assert fn(C.byref(p), s) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn(C.byref(p), s)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    return ms, 2.0 * Mtot * N * K / (ms * 1e-3) / 1e12, splits
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--tiles", default="128,256,384,0")
     ap.add_argument("--act", type=int, default=0)
+    ap.add_argument("--tn", action="store_true")
+    ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--small", action="store_true")
     args = ap.parse_args()
     L = _lib.lib()
+    if args.tn:
+        for big in ((1,) if args.quick else (0, 1)):
+            for (M, N, K) in (TN_SHAPES[:2] if args.quick else TN_SHAPES[4:] if args.small else TN_SHAPES):
+                ms, tf, sp = time_tn(L, M, N, K, big, iters=2 if args.quick else 20 if args.small else 5)
+                print(f"tn big={big} Mtot {M} N {N:5d} K {K:5d} splits {sp:3d}  {ms*1e3:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
+        return
     for tile in [int(t) for t in args.tiles.split(",")]:
         L.plb_set_gemm_nt_tile(tile)
         for (M, N, K) in SHAPES:
