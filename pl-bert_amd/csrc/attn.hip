@@ -148,30 +148,39 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(PlbAttn p) {
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, 0, ks, lane), qf[ks], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, 1, ks, lane), qf[ks], s1, 0, 0, 0);
     }
-    // scale into the exp2 domain, mask padded keys, tile max for this lane's query
-    const int kbase_i = kt * 64 + 4 * h;
+    // Softmax in the exp2 domain. The loop is VALU-bound at head_dim 64 (one v_exp per score against
+    // 256 MFMA flops), so: masking only in a tile that crosses the length, the scale folded into one
+    // FMA per score (max taken on raw scores: the scale is positive), and the accumulator rescaled only
+    // when some query's running max actually moved (exact: alpha == 1 otherwise).
     float mx = -INFINITY;
+    if (kt * 64 + 64 > len) {
+      const int kbase_i = kt * 64 + 4 * h;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int kr0 = kbase_i + (r & 3) + 8 * (r >> 2);
-      s0[r] = (kr0 < len) ? s0[r] * sl2 : -INFINITY;
-      s1[r] = (kr0 + 32 < len) ? s1[r] * sl2 : -INFINITY;
-      mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+      for (int r = 0; r < 16; ++r) {
+        const int kr0 = kbase_i + (r & 3) + 8 * (r >> 2);
+        s0[r] = (kr0 < len) ? s0[r] : -INFINITY;
+        s1[r] = (kr0 + 32 < len) ? s1[r] : -INFINITY;
+      }
     }
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(fmaxf(s0[r], s0[r + 1]), fmaxf(s1[r], s1[r + 1])));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);   // finite: the first tile always holds key 0 < len
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    const float m_new = fmaxf(m_run, mx * sl2);   // finite: the first tile always holds key 0 < len
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      m_run = m_new;
+    }
     float ls = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-      s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+      s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -m_new));
+      s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -m_new));
       ls += s0[r] + s1[r];
     }
-    l_run = l_run * alpha + ls;
-    m_run = m_new;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+    l_run += ls;
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const bf16x8 pb = acc_frag((s4 >> 1) ? s1 : s0, s4 & 1);
@@ -272,10 +281,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(PlbAttn p) {
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, kb, ks, lane), dof[ks], dp, 0, 0, 0);
       }
       const int kb0 = kt * 64 + kb * 32 + 4 * h;
+      if (kt * 64 + 64 > len) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb0 + (r & 3) + 8 * (r >> 2);
+          s[r] = (key < len) ? s[r] : -INFINITY;   // exp2(-inf) = 0
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kb0 + (r & 3) + 8 * (r >> 2);
-        const float pr = (key < len) ? __builtin_amdgcn_exp2f(s[r] * sl2 - lse2) : 0.f;
+        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -lse2));
         s[r] = pr * (dp[r] - delta);   // dS^T (scale applied once at the end)
       }
 #pragma unroll
@@ -366,6 +381,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(PlbAttn p) {
     Q_LOAD(qt + 1 < nqt ? qt + 1 : qt);
     const bf16_t* sQ = smem[cur][0];
     const bf16_t* sQt = smem[cur][1];
+    const bool need_mask = (key0 + 32 > len) || (qt * 64 + 64 > len);  // wave-uniform
     const bf16_t* sDO = smem[cur][2];
     const bf16_t* sDOt = smem[cur][3];
 #pragma unroll
@@ -387,8 +403,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(PlbAttn p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = 4 * rg + j;
-          const bool ok = key_ok && (qt * 64 + ql + j < len);
-          const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * sl2 - lv[j]) : 0.f;
+          float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -lv[j]));
+          if (need_mask) pr = (key_ok && (qt * 64 + ql + j < len)) ? pr : 0.f;
           s[r] = pr;
           ds[r] = pr * (dp[r] - dv[j]);
         }
