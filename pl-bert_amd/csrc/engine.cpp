@@ -105,7 +105,7 @@ struct PlbEngine {
   int64_t o_dqkv, o_dpre1, o_du, o_dpre2;
   int64_t o_dy0, o_dy1, o_da, o_dctx, o_de;
   int64_t o_hm, o_logm, o_dlog, o_dhm, o_rows, o_tgt, o_w, o_lrows;
-  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_logfull;
+  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_logfull, o_dxe;
   int64_t slab_floats;
   int64_t ws_bytes;
   int ln_blocks, emb_blocks;
@@ -190,8 +190,8 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   const int64_t Tp = rup(T, 128);
   e->Tcap = Tp;
   e->NMcap = Tp;
-  e->ln_blocks = 512;
-  e->emb_blocks = 256;
+  e->ln_blocks = 1024;
+  e->emb_blocks = 2048;
   Carve cv;
   // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes
   e->o_wbf = cv.take((e->ptotal + 256 * (H > I ? H : I)) * 2);
@@ -246,9 +246,10 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   }
   e->slab_floats = slab;
   e->o_slab = cv.take(slab * 4);
-  e->o_part1 = cv.take(L * e->ln_blocks * 3 * H * 4);  // per LN-backward block: dgamma | dbeta | colsum(dx)
-  e->o_part2 = cv.take(L * e->ln_blocks * 3 * H * 4);
+  e->o_part1 = cv.take(L * e->ln_blocks * 2 * H * 4);  // per LN-backward block: dgamma | dbeta
+  e->o_part2 = cv.take(L * e->ln_blocks * 2 * H * 4);
   e->o_parte = cv.take((int64_t)e->emb_blocks * 2 * E * 4);
+  e->o_dxe = cv.take(Tp * E * 4);
   e->o_scratch = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);  // colsum partials: up to 512 row splits
   e->ws_bytes = cv.off;
   *out = e;
@@ -508,7 +509,7 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
     ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
     ln.mean = e->at<float>(e->o_mean2) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd2) + (int64_t)l * Tp;
     ln.dy = dy; ln.lddy = H; ln.dx = dpre2; ln.lddx = H;
-    ln.partials = e->at<float>(e->o_part2) + (int64_t)l * e->ln_blocks * 3 * H; ln.nblocks = e->ln_blocks;
+    ln.partials = e->at<float>(e->o_part2) + (int64_t)l * e->ln_blocks * 2 * H; ln.nblocks = e->ln_blocks;
     TRY(plb_launch_ln_bwd(&ln, s));
     // dU = (dpre2 · W2) ∘ gelu'(u)
     memset(&g, 0, sizeof(g));
@@ -524,7 +525,7 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
     ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
     ln.mean = e->at<float>(e->o_mean1) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd1) + (int64_t)l * Tp;
     ln.dy = da; ln.lddy = H; ln.dx = dpre1; ln.lddx = H;
-    ln.partials = e->at<float>(e->o_part1) + (int64_t)l * e->ln_blocks * 3 * H; ln.nblocks = e->ln_blocks;
+    ln.partials = e->at<float>(e->o_part1) + (int64_t)l * e->ln_blocks * 2 * H; ln.nblocks = e->ln_blocks;
     TRY(plb_launch_ln_bwd(&ln, s));
     // dCtx = dpre1 · Wd
     memset(&g, 0, sizeof(g));
@@ -555,15 +556,17 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   TRY(plb_launch_gemm_nt(&g, 0, 0, s));
   if (weight_grad(e, dy, H, H, evec, E, Tp, H, E, e->grd(PLB_MAP_W), s)) return 1;
   TRY(plb_launch_colsum(dy, 1, (size_t)Tp, H, H, e->grd(PLB_MAP_B), H, 0, scratch, 128, s));
-  HIPTRY(hipMemsetAsync(e->grd(PLB_WORD_EMB), 0, (size_t)(e->psize[PLB_WORD_EMB] + e->psize[PLB_POS_EMB] + e->psize[PLB_TYPE_EMB]) * 4, s));
+  HIPTRY(hipMemsetAsync(e->grd(PLB_TYPE_EMB), 0, (size_t)e->psize[PLB_TYPE_EMB] * 4, s));
   PlbEmbed em;
   memset(&em, 0, sizeof(em));
   em.ids = masked_ids; em.T = T; em.S = S; em.E = E; em.V = e->V;
   em.word = e->par(PLB_WORD_EMB); em.pos = e->par(PLB_POS_EMB); em.type0 = e->par(PLB_TYPE_EMB);
   em.gamma = e->par(PLB_EMB_LN_W); em.beta = e->par(PLB_EMB_LN_B); em.eps = e->c.layer_norm_eps;
   em.dout = de; em.lddo = E; em.dword = e->grd(PLB_WORD_EMB); em.dpos = e->grd(PLB_POS_EMB);
+  em.dx = e->at<float>(e->o_dxe);
   em.partials = e->at<float>(e->o_parte); em.nblocks = e->emb_blocks;
   TRY(plb_launch_embed_bwd(&em, s));
+  TRY(plb_launch_embed_scatter(&em, e->P, s));
   TRY(plb_launch_colsum(em.partials, 0, (size_t)e->emb_blocks, 2 * E, 2 * E, e->grd(PLB_EMB_LN_W), 2 * E, 0, scratch, 1, s));
   // token_type row 0 receives every token's gradient = the column sums of dpos
   TRY(plb_launch_colsum(e->grd(PLB_POS_EMB), 0, (size_t)e->P, E, E, e->grd(PLB_TYPE_EMB), E, 0, scratch, 1, s));
@@ -574,15 +577,13 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   if (weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dqkv), 1, (size_t)Mtot, 3 * H, 3 * H, e->grd(PLB_Q_B), 3 * H, 0, scratch, 128, s));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 128, s));
-  // LayerNorm-backward partials [L*blocks][3H]: dgamma|dbeta -> the LN parameters, colsum(dx) -> the bias
-  // of the Linear whose output (+residual) the LN normalises (dense for LN1, ffn_output for LN2)
-  const size_t prow = (size_t)L * e->ln_blocks;
-  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 2 * H, 3 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch, 16, s));
-  TRY(plb_launch_colsum(e->at<float>(e->o_part1) + 2 * H, 0, prow, H, 3 * H, e->grd(PLB_DENSE_B), H, 0, scratch, 16, s));
-  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 2 * H, 3 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch, 16, s));
-  TRY(plb_launch_colsum(e->at<float>(e->o_part2) + 2 * H, 0, prow, H, 3 * H, e->grd(PLB_FFNO_B), H, 0, scratch, 16, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dqkv), 1, (size_t)Mtot, 3 * H, 3 * H, e->grd(PLB_Q_B), 3 * H, 0, scratch, 64, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 64, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre1), 1, (size_t)Mtot, H, H, e->grd(PLB_DENSE_B), H, 0, scratch, 128, s));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre2), 1, (size_t)Mtot, H, H, e->grd(PLB_FFNO_B), H, 0, scratch, 128, s));
+  const size_t prow = (size_t)L * e->ln_blocks;  // LayerNorm-backward partials [L*blocks][2H]: dgamma | dbeta
+  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 2 * H, 2 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch, 16, s));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 2 * H, 2 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch, 16, s));
   return 0;
 }
 

@@ -56,12 +56,14 @@ typedef struct {
   bf16_t* out; int ldo;
   // backward
   const bf16_t* dout; int lddo;
-  float *dword, *dpos;          // fp32 [V,E], [P,E] accumulated with atomics (zeroed by the caller)
+  float* dx;                    // fp32 [T,E]: gradient of the pre-LayerNorm embedding sum (written by embed_bwd)
+  float *dword, *dpos;          // fp32 [V,E], [P,E]: written by embed_scatter (every row, no atomics)
   float* partials;              // [nblocks][2E] : dgamma | dbeta partial sums
   int nblocks;
 } PlbEmbed;
 int plb_launch_embed_fwd(const PlbEmbed* p, hipStream_t stream);
-int plb_launch_embed_bwd(const PlbEmbed* p, hipStream_t stream);  // grid = p->nblocks
+int plb_launch_embed_bwd(const PlbEmbed* p, hipStream_t stream);  // grid = p->nblocks; writes dx + partials
+int plb_launch_embed_scatter(const PlbEmbed* p, int P, hipStream_t stream);  // dx -> dword [V,E], dpos [P,E]
 
 // LayerNorm over rows of width H (H%4==0, H<=1024): y = LN(x)*g+b ; stats saved for the backward
 typedef struct {
@@ -71,7 +73,7 @@ typedef struct {
   float *mean, *rstd;           // [T]
   int T, H;
   int Tzero;                    // backward: rows T..Tzero-1 of dx are written as zeros
-  // backward: dx = LN'(dy); partials[nblocks][3H] = dgamma | dbeta | column sums of dx
+  // backward: dx = LN'(dy); partials[nblocks][2H] = dgamma | dbeta
   const bf16_t* dy; int lddy;
   bf16_t* dx; int lddx;
   float* partials; int nblocks;

@@ -61,19 +61,10 @@ __global__ __launch_bounds__(256) void embed_kernel(PlbEmbed p) {
         dg[j] += dy[j] * xh[j]; db[j] += dy[j];
       }
       s1 = wave_sum(s1) * invE; s2 = wave_sum(s2) * invE;
-      if (act) {
-        float dx[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dx[j] = rstd * (dxh[j] - s1 - xh[j] * s2);
-        float* dp = p.dpos + (size_t)s * E + c;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(dp + j, dx[j]);
-        if (id != 0) {  // nn.Embedding(padding_idx=0): the pad row gets no gradient
-          float* dw = p.dword + (size_t)id * E + c;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) atomicAdd(dw + j, dx[j]);
-        }
-      }
+      if (act)  // gradient of the pre-LayerNorm sum, consumed by embed_scatter_kernel (no atomics)
+        *(float4*)(p.dx + (size_t)t * E + c) =
+            make_float4(rstd * (dxh[0] - s1 - xh[0] * s2), rstd * (dxh[1] - s1 - xh[1] * s2),
+                        rstd * (dxh[2] - s1 - xh[2] * s2), rstd * (dxh[3] - s1 - xh[3] * s2));
     }
   }
   if (BWD) {
@@ -88,6 +79,71 @@ __global__ __launch_bounds__(256) void embed_kernel(PlbEmbed p) {
       p.partials[(size_t)blockIdx.x * 2 * E + i] =
           red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
     }
+  }
+}
+
+// Scatter-add of the embedding gradient without atomics (deterministic): block v < V owns word row v
+// (collects the tokens whose id is v into an LDS list, then sums their dx rows in token order), block
+// V + s owns position row s (sum over the batch). Row 0 of the word table is the padding row
+// (nn.Embedding(padding_idx=0), modeling_albert.py:56): no gradient.
+__global__ __launch_bounds__(256) void embed_scatter_kernel(PlbEmbed p, int P) {
+  extern __shared__ int list[];  // 4 per-wave segments of matching token indices
+  __shared__ int wcnt[4];
+  __shared__ float4 part[256];
+  const int E = p.E, T = p.T;
+  const int row = blockIdx.x;
+  const int EQ = E >> 2;                                   // float4 columns per row
+  const int q = threadIdx.x % EQ, grp = threadIdx.x / EQ, ngrp = 256 / EQ;  // E = 128: 32 x 8
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add = [&](int t) {
+    const float4 v = *(const float4*)(p.dx + (size_t)t * E + 4 * q);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  };
+  if (row < p.V) {
+    // each wave scans its own quarter of the tokens (64-token chunks, round-robin) and appends the
+    // matches to its own list segment: no block barrier inside the scan. Fixed order -> deterministic.
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cap = (T + 3) / 4 + 64;
+    int cnt = 0;
+    if (row != 0) {
+      for (int t0 = w * 64; t0 < T; t0 += 256) {
+        const int t = t0 + lane;
+        const bool hit = t < T && p.ids[t] == row;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        if (hit) list[w * cap + cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
+        cnt += __builtin_popcountll(m);
+      }
+    }
+    if (lane == 0) wcnt[w] = cnt;
+    __syncthreads();
+    // a few ids (separator, mask) own thousands of tokens: ngrp row groups x 4 loads in flight each
+    for (int ww = 0; ww < 4; ++ww) {
+      const int n = wcnt[ww];
+      const int* l = list + ww * cap;
+      int i = grp;
+      for (; i + 3 * ngrp < n; i += 4 * ngrp) {
+        const int t0 = l[i], t1 = l[i + ngrp], t2 = l[i + 2 * ngrp], t3 = l[i + 3 * ngrp];
+        const float4 v0 = *(const float4*)(p.dx + (size_t)t0 * E + 4 * q), v1 = *(const float4*)(p.dx + (size_t)t1 * E + 4 * q);
+        const float4 v2 = *(const float4*)(p.dx + (size_t)t2 * E + 4 * q), v3 = *(const float4*)(p.dx + (size_t)t3 * E + 4 * q);
+        s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+        s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+      }
+      for (; i < n; i += ngrp) add(l[i]);
+    }
+  } else {
+    const int sidx = row - p.V;  // position row: sum over the batch
+    if (sidx < p.S)
+      for (int t = sidx + grp * p.S; t < T; t += ngrp * p.S) add(t);
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (grp == 0) {
+    for (int g = 1; g < ngrp; ++g) {
+      const float4 v = part[g * EQ + q];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (row < p.V) *(float4*)(p.dword + (size_t)row * E + 4 * q) = s;
+    else if (row - p.V < P) *(float4*)(p.dpos + (size_t)(row - p.V) * E + 4 * q) = s;
   }
 }
 
@@ -138,18 +194,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(PlbLayerNorm p) {
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
-  __shared__ float red[4][3][1024];
+  __shared__ float red[4][2][NCH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = p.H;
   const float invH = 1.0f / (float)H;
-  float dg[NCH][4], db[NCH][4], gm[NCH][4], ds[NCH][4];
+  float dg[NCH][4], db[NCH][4], gm[NCH][4];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = (lane + 64 * i) * 4;
     float4 g = (c < H) ? *(const float4*)(p.gamma + c) : make_float4(0, 0, 0, 0);
     gm[i][0] = g.x; gm[i][1] = g.y; gm[i][2] = g.z; gm[i][3] = g.w;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = ds[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
   }
   for (int t = blockIdx.x * 4 + wave; t < p.T; t += gridDim.x * 4) {
     const float mean = p.mean[t], rstd = p.rstd[t];
@@ -182,8 +238,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
         o.x = pack_bf2(rstd * (dxh[i][0] - s1 - xh[i][0] * s2), rstd * (dxh[i][1] - s1 - xh[i][1] * s2));
         o.y = pack_bf2(rstd * (dxh[i][2] - s1 - xh[i][2] * s2), rstd * (dxh[i][3] - s1 - xh[i][3] * s2));
         *(uint2*)(p.dx + (size_t)t * p.lddx + c) = o;
-        // column sums of the ROUNDED dx: exactly what a column sum over the stored bf16 tensor gives
-        ds[i][0] += bf_lo(o.x); ds[i][1] += bf_hi(o.x); ds[i][2] += bf_lo(o.y); ds[i][3] += bf_hi(o.y);
       }
     }
   }
@@ -200,15 +254,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        red[wave][0][c + j] = dg[i][j]; red[wave][1][c + j] = db[i][j]; red[wave][2][c + j] = ds[i][j];
-      }
+      for (int j = 0; j < 4; ++j) { red[wave][0][c + j] = dg[i][j]; red[wave][1][c + j] = db[i][j]; }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 3 * H; i += 256) {
+  for (int i = threadIdx.x; i < 2 * H; i += 256) {
     const int which = i / H, col = i % H;
-    p.partials[(size_t)blockIdx.x * 3 * H + i] =
+    p.partials[(size_t)blockIdx.x * 2 * H + i] =
         red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
   }
 }
@@ -287,12 +339,19 @@ __global__ void reduce_slabs_kernel(const float* slab, int splits, size_t n, flo
   }
 }
 
-__global__ void reduce_cols_kernel(const float* scratch, int nsplit, int N, int Nout, float* out, int accumulate) {
-  const int j0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  for (int j = j0; j < j0 + 4 && j < Nout; ++j) {
-    float s = accumulate ? out[j] : 0.f;
-    for (int k = 0; k < nsplit; ++k) s += scratch[(size_t)k * N + j];
-    out[j] = s;
+__global__ __launch_bounds__(256) void reduce_cols_kernel(const float* scratch, int nsplit, int N, int Nout, float* out,
+                                                          int accumulate) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (j < Nout)
+    for (int k = g; k < nsplit; k += 4) s += scratch[(size_t)k * N + j];  // fixed order per column
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0 && j < Nout) {
+    const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    out[j] = accumulate ? out[j] + t : t;
   }
 }
 
@@ -450,6 +509,12 @@ extern "C" int plb_launch_embed_fwd(const PlbEmbed* p, hipStream_t stream) {
   hipLaunchKernelGGL((embed_kernel<false>), dim3(blocks), dim3(256), 0, stream, *p);
   return LAUNCH_OK();
 }
+extern "C" int plb_launch_embed_scatter(const PlbEmbed* p, int P, hipStream_t stream) {
+  if ((p->E != 64 && p->E != 128 && p->E != 256) || p->T <= 0 || (size_t)p->T * 4 > 150 * 1024) return 1;
+  ProfScope ps(PLB_K_EMBED_BWD, stream, 0, (double)p->T * p->E * 8.0);
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(p->V + P), dim3(256), (size_t)(((p->T + 3) / 4 + 64) * 4) * 4, stream, *p, P);
+  return LAUNCH_OK();
+}
 extern "C" int plb_launch_embed_bwd(const PlbEmbed* p, hipStream_t stream) {
   if (p->E % 4 || p->E > 256 || p->T <= 0 || p->nblocks <= 0) return 1;
   ProfScope ps(PLB_K_EMBED_BWD, stream, 0, (double)p->T * (8 + 2.0 * p->E + 8.0 * p->E));
@@ -498,9 +563,8 @@ extern "C" int plb_launch_colsum(const void* X, int is_bf16, size_t R, int N, in
   if (is_bf16) hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, stream, X, R, N, ld, scratch, nsplit);
   else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, stream, X, R, N, ld, scratch, nsplit);
   if (hipGetLastError() != hipSuccess) return 2;
-  const size_t threads = ((size_t)Nout + 3) / 4;
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, scratch, nsplit,
-                     N, Nout, out, accumulate);
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)((Nout + 63) / 64)), dim3(256), 0, stream, scratch, nsplit, N,
+                     Nout, out, accumulate);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_gather_rows(const bf16_t* src, int lds_, const int32_t* rows, int n, int npad, int H,
