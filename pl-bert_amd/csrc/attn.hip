@@ -85,7 +85,7 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
 }
 
 // ---------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(256) void attn_fwd_kernel(PlbAttn p) {
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(PlbAttn p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][64 * 64];  // [stage][K row | V tr] 32 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(PlbAttn p) {
 }
 
 // ------------------------------------------------------------------------------------- backward dQ
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(PlbAttn p) {
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][3][64 * 64];  // [stage][K row | K tr | V row] 48 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(PlbAttn p) {
 }
 
 // ---------------------------------------------------------------------------------- backward dK,dV
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(PlbAttn p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   // [stage][Q row | Q tr | dO row | dO tr] + lse/delta rows
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][4][64 * 64];  // 64 KiB
   __shared__ __attribute__((aligned(16))) float sstat[2][2][64];       // [stage][lse*log2e | delta][q]
@@ -392,8 +392,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(PlbAttn p) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, qb, ks, lane), kf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sDO, qb, ks, lane), vf[ks], dp, 0, 0, 0);
       }
-      // s[r] = S[q][key]: key on the lane, q = qt*64 + qb*32 + (r&3) + 8(r>>2) + 4h
-      f32x16 ds;
+      // s[r] = S[q][key]: key on the lane, q = qt*64 + qb*32 + (r&3) + 8(r>>2) + 4h; dS overwrites dP
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int ql = qb * 32 + 8 * rg + 4 * h;
@@ -406,12 +405,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(PlbAttn p) {
           float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -lv[j]));
           if (need_mask) pr = (key_ok && (qt * 64 + ql + j < len)) ? pr : 0.f;
           s[r] = pr;
-          ds[r] = pr * (dp[r] - dv[j]);
+          dp[r] = pr * (dp[r] - dv[j]);
         }
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pb = acc_frag(s, s2), dsb = acc_frag(ds, s2);
+        const bf16x8 pb = acc_frag(s, s2), dsb = acc_frag(dp, s2);
         dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDOt, qb, s2, 0, lane), pb, dv0, 0, 0, 0);
         dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDOt, qb, s2, 1, lane), pb, dv1, 0, 0, 0);
         dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQt, qb, s2, 0, lane), dsb, dk0, 0, 0, 0);
