@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group and run the gradient all-reduce even at world size 1 "
+                         "(rehearses the N>1 code path on a one-GPU box)")
     return ap.parse_args()
 
 
@@ -89,7 +92,8 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run
+    if world > 1 or (launched and args.force_dist):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
@@ -98,12 +102,12 @@ def main():
                                   intermediate_size=2048, max_position_embeddings=512, num_hidden_layers=12)
     B, S = args.batch, args.seq
     trainer = PLBertTrainer(cfg, num_phonemes=len(plbert_amd.symbols), max_batch=B, max_seq=S, lr=7e-5,
-                            device=f"cuda:{local_rank}", seed=0)
+                            device=f"cuda:{local_rank}", seed=0, force_collectives=args.force_dist)
     labels, masked, lengths, idx = plbert_amd.synthetic_batch(B, S, seed=1234 + rank)
     batch = trainer.stage_batch(labels, masked, lengths, idx)  # resident in HBM before timing
 
     def sync_all():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -162,7 +166,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

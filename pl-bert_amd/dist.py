@@ -35,22 +35,24 @@ class GradReducer:
     """Sum all-reduce of a flat gradient tensor, optionally in contiguous pieces on a side stream so a
     piece can be reduced while later kernels of the backward still run on the main stream."""
 
-    def __init__(self, group=None, device=None):
+    def __init__(self, group=None, device=None, force=False):
         self.group = group
         self.rank, self.world = world_info(group)
+        # force: issue the collectives even at world size 1 (rehearsal of the N > 1 path on one GPU)
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
         self.stream = None
-        if self.world > 1 and device is not None and torch.device(device).type == "cuda":
+        if self.active and device is not None and torch.device(device).type == "cuda":
             self.stream = torch.cuda.Stream(device=device)
 
     def broadcast_(self, flat, src=0):
-        if self.world > 1:
+        if self.active:
             dist.broadcast(flat, src=dist.get_global_rank(self.group, src) if self.group is not None else src,
                            group=self.group)
 
     def all_reduce_(self, flat, pieces=None):
         """flat: 1-D tensor; pieces: optional list of (begin, end) element ranges reduced as separate
         collectives (default: the whole tensor in one)."""
-        if self.world == 1:
+        if not self.active:
             return
         pieces = pieces or [(0, flat.numel())]
         if self.stream is None:

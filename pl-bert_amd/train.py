@@ -60,15 +60,15 @@ class PLBertTrainer:
     """PhonemeOnlyModel + AdamW(lr) of train.py:266-272 on one GPU, optionally data parallel."""
 
     def __init__(self, cfg, num_phonemes, max_batch=32, max_seq=512, lr=7e-5, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.01, device=None, seed=0, state_dict=None, process_group=None):
+                 weight_decay=0.01, device=None, seed=0, state_dict=None, process_group=None, force_collectives=False):
         self.engine = HipEngine(cfg, num_phonemes, 0, max_batch=max_batch, max_seq=max_seq, device=device)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
-        self.reducer = GradReducer(process_group, device=self.engine.device)
+        self.reducer = GradReducer(process_group, device=self.engine.device, force=force_collectives)
         self.world = self.reducer.world
         sd = state_dict if state_dict is not None else reference_init_state_dict(cfg, num_phonemes, 0, seed=seed)
         self.engine.load_state_dict(sd)
-        if self.world > 1:  # DDP's start-up broadcast of rank 0's parameters (SURVEY.md §2 row 7 (i))
+        if self.reducer.active:  # DDP's start-up broadcast of rank 0's parameters (SURVEY.md §2 row 7 (i))
             self.reducer.broadcast_(self.engine.params)
             self.engine.sync_weights()
 
