@@ -72,6 +72,7 @@ class PlbGemmNT(C.Structure):
         ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("Mstore", C.c_int),
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_int), ("aux", C.c_void_p), ("ldaux", C.c_int),
         ("C", C.c_void_p), ("ldc", C.c_int), ("C2", C.c_void_p), ("ldc2", C.c_int), ("Cf", C.c_void_p), ("ldcf", C.c_int),
+        ("colpart", C.c_void_p),
     ]
 
 

@@ -105,7 +105,7 @@ struct PlbEngine {
   int64_t o_dqkv, o_dpre1, o_du, o_dpre2;
   int64_t o_dy0, o_dy1, o_da, o_dctx, o_de;
   int64_t o_hm, o_logm, o_dlog, o_dhm, o_rows, o_tgt, o_w, o_lrows;
-  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_logfull, o_dxe;
+  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_logfull, o_dxe, o_ducol;
   int64_t slab_floats;
   int64_t ws_bytes;
   int ln_blocks, emb_blocks;
@@ -250,6 +250,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   e->o_part2 = cv.take(L * e->ln_blocks * 2 * H * 4);
   e->o_parte = cv.take((int64_t)e->emb_blocks * 2 * E * 4);
   e->o_dxe = cv.take(Tp * E * 4);
+  e->o_ducol = cv.take(L * (2 * Tp / 128) * I * 4);  // column-sum partials of dU from the GEMM epilogue
   e->o_scratch = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);  // colsum partials: up to 512 row splits
   e->ws_bytes = cv.off;
   *out = e;
@@ -491,6 +492,7 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   TRY(plb_launch_scatter_rows(dhm, H, rows, n_masked, H, dy, H, s));
 
   // ---- layers in reverse --------------------------------------------------------------------------------
+  const int du_rows = plb_gemm_nt_colpart_rows((int)Tp, I, H);  // ffn.bias gradient from the dU GEMM's epilogue
   bf16_t* da = e->at<bf16_t>(e->o_da);
   bf16_t* dctx = e->at<bf16_t>(e->o_dctx);
   for (int l = L - 1; l >= 0; --l) {
@@ -515,6 +517,7 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
     memset(&g, 0, sizeof(g));
     g.A = dpre2; g.lda = H; g.B = e->at<bf16_t>(e->o_w2T); g.ldb = H; g.M = (int)Tp; g.N = I; g.K = H; g.Mstore = (int)Tp;
     g.aux = u; g.ldaux = I; g.C = du; g.ldc = I;
+    if (du_rows > 0) g.colpart = e->at<float>(e->o_ducol) + (int64_t)l * du_rows * I;
     TRY(plb_launch_gemm_nt(&g, 2, 0, s));
     // dA = dU · W1 + dpre2
     memset(&g, 0, sizeof(g));
@@ -578,7 +581,10 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   if (weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
   TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dqkv), 1, (size_t)Mtot, 3 * H, 3 * H, e->grd(PLB_Q_B), 3 * H, 0, scratch, 64, s));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 64, s));
+  if (du_rows > 0)
+    TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 16, s));
+  else
+    TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 64, s));
   TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre1), 1, (size_t)Mtot, H, H, e->grd(PLB_DENSE_B), H, 0, scratch, 128, s));
   TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre2), 1, (size_t)Mtot, H, H, e->grd(PLB_FFNO_B), H, 0, scratch, 128, s));
   const size_t prow = (size_t)L * e->ln_blocks;  // LayerNorm-backward partials [L*blocks][2H]: dgamma | dbeta

@@ -233,12 +233,22 @@ static int pick_tile(const PlbGemmNT* p) {
   return e384 > e256 ? 384 : 256;
 }
 
+// Rows of column-sum partials (PlbGemmNT.colpart) the launch of this shape writes: 2 per row tile of
+// the big-tile kernel picked for it, 0 when the shape runs on the 128x128 kernel (no partials there).
+extern "C" int plb_gemm_nt_colpart_rows(int M, int N, int K) {
+  PlbGemmNT q;
+  q.M = M; q.N = N; q.K = K;
+  const int tile = pick_tile(&q);
+  return tile == 256 ? 2 * (M / 256) : tile == 384 ? 2 * (M / 128) : 0;
+}
+
 extern "C" int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {
   if (p->M % BM || p->K % BK || p->N % 4 || p->M <= 0 || p->N <= 0 || p->K <= 0) return 1;
   const int nbn = (p->N + BN - 1) / BN;
   dim3 grid((p->M / BM) * nbn), block(256);
   const int cls = out_f32 ? PLB_K_GEMM_NT_F32 : act == 1 ? PLB_K_GEMM_NT_GELU : act == 2 ? PLB_K_GEMM_NT_GELUBWD : PLB_K_GEMM_NT;
   const int tile = pick_tile(p);
+  if (p->colpart && tile == 128) return 1;  // column-sum partials exist in the big-tile kernels only
   if (tile != 128) {
     const int tokb = plb_prof_begin(cls, stream, 2.0 * (double)p->M * p->N * p->K, 0.0);
     const int rc = plb_launch_gemm_nt_big(p, tile, act, out_f32, stream);

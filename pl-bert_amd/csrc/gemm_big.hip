@@ -193,17 +193,92 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #undef MFMA_PART
 #undef LANDED
 
+  // ---- epilogue. Loads are batched per 16-row slab — all bias vectors once, then the residual / aux
+  // segments of one slab together — so a slab costs ONE memory round trip instead of one per 16x16
+  // tile (the straightforward per-tile form serialises 2 dependent loads x 24-32 tiles per lane).
+  // Big-tile shapes have N % TN == 0; rows >= Mstore are computed but not stored.
+  f32x4 csum[NBH][2];  // column sums of this wave's rows (only when p.colpart is set)
+  float4 bz[NBH][2];
+#pragma unroll
+  for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      csum[nh][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+      bz[nh][ni] = p.bias ? *(const float4*)(p.bias + bn * TN + nh * 128 + wn * 32 + ni * 16 + fq * 4)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  const int ncol0 = bn * TN + wn * 32 + fq * 4;
 #pragma unroll
   for (int mh = 0; mh < NAH; ++mh)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const int m = bm * TM + mh * 128 + wm * 64 + mi * 16 + frow;
+      uint2 rr[NBH][2], ux[NBH][2];
+      if (p.res) {
+#pragma unroll
+        for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            rr[nh][ni] = *(const uint2*)(p.res + (size_t)m * p.ldr + ncol0 + nh * 128 + ni * 16);
+      }
+      if (ACT == 2) {
+#pragma unroll
+        for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+            ux[nh][ni] = *(const uint2*)(p.aux + (size_t)m * p.ldaux + ncol0 + nh * 128 + ni * 16);
+      }
+      const bool st = m < p.Mstore;
 #pragma unroll
       for (int nh = 0; nh < NBH; ++nh)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-          nt_epilogue<ACT, OUTF32>(p, acc[mh][mi][nh][ni], m, bn * TN + nh * 128 + wn * 32 + ni * 16 + fq * 4);
+        for (int ni = 0; ni < 2; ++ni) {
+          f32x4 v = acc[mh][mi][nh][ni];
+          const int n0 = ncol0 + nh * 128 + ni * 16;
+          v[0] += bz[nh][ni].x; v[1] += bz[nh][ni].y; v[2] += bz[nh][ni].z; v[3] += bz[nh][ni].w;
+          if (p.res) {
+            v[0] += bf_lo(rr[nh][ni].x); v[1] += bf_hi(rr[nh][ni].x);
+            v[2] += bf_lo(rr[nh][ni].y); v[3] += bf_hi(rr[nh][ni].y);
+          }
+          if (ACT == 2) {  // gelu backward: multiply by gelu_new'(u)
+            v[0] *= gelu_new_grad_f(bf_lo(ux[nh][ni].x)); v[1] *= gelu_new_grad_f(bf_hi(ux[nh][ni].x));
+            v[2] *= gelu_new_grad_f(bf_lo(ux[nh][ni].y)); v[3] *= gelu_new_grad_f(bf_hi(ux[nh][ni].y));
+          }
+          if (OUTF32) {
+            if (st) *(float4*)(p.Cf + (size_t)m * p.ldcf + n0) = make_float4(v[0], v[1], v[2], v[3]);
+          } else {
+            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+            if (st) *(uint2*)(p.C + (size_t)m * p.ldc + n0) = o;
+            if (ACT == 1) {  // gelu forward: C keeps the bf16 pre-activation u, C2 = gelu_new(u)
+              uint2 g;
+              g.x = pack_bf2(gelu_new_f(bf_lo(o.x)), gelu_new_f(bf_hi(o.x)));
+              g.y = pack_bf2(gelu_new_f(bf_lo(o.y)), gelu_new_f(bf_hi(o.y)));
+              if (st) *(uint2*)(p.C2 + (size_t)m * p.ldc2 + n0) = g;
+            }
+            v = f32x4{bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};  // the values as stored
+          }
+          if (st) csum[nh][ni] += v;
+        }
     }
+  if (p.colpart) {
+    // Bias gradient of the producing Linear for free: sum the stored values over this wave's 64*NAH rows
+    // (16 lanes hold 16 different rows of the same 4 columns) and write ONE partial row per (row tile, wm):
+    // colpart[(bm*2 + wm)][n]; a fixed-order column sum over these few rows finishes it (deterministic).
+#pragma unroll
+    for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        f32x4 v = csum[nh][ni];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          v[0] += __shfl_xor(v[0], o, 64); v[1] += __shfl_xor(v[1], o, 64);
+          v[2] += __shfl_xor(v[2], o, 64); v[3] += __shfl_xor(v[3], o, 64);
+        }
+        if (frow == 0)
+          *(float4*)(p.colpart + (size_t)(bm * 2 + wm) * p.N + bn * TN + nh * 128 + wn * 32 + ni * 16 + fq * 4) =
+              make_float4(v[0], v[1], v[2], v[3]);
+      }
+  }
 }
 
 template <int NBH>

@@ -4,10 +4,11 @@
 #include "plbert_kernels.h"
 
 // v = acc (+bias) (+residual) (*gelu_new'(aux) when ACT == 2) -> bf16 C (and C2 = gelu_new(C) when
-// ACT == 1) or fp32 Cf. Rows >= Mstore and columns >= N are not stored.
+// ACT == 1) or fp32 Cf. Rows >= Mstore and columns >= N are not stored. Returns the values as stored
+// (bf16-rounded for bf16 outputs; zeros when nothing was stored) so callers can form column sums.
 template <int ACT, bool OUTF32>
-DEVI void nt_epilogue(const PlbGemmNT& p, f32x4 v, int m, int n0) {
-  if (m >= p.Mstore || n0 >= p.N) return;
+DEVI f32x4 nt_epilogue(const PlbGemmNT& p, f32x4 v, int m, int n0) {
+  if (m >= p.Mstore || n0 >= p.N) return f32x4{0.f, 0.f, 0.f, 0.f};
   if (p.bias) {
     float4 b = *(const float4*)(p.bias + n0);
     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
@@ -23,6 +24,7 @@ DEVI void nt_epilogue(const PlbGemmNT& p, f32x4 v, int m, int n0) {
   }
   if (OUTF32) {
     *(float4*)(p.Cf + (size_t)m * p.ldcf + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    return v;
   } else {
     uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
     *(uint2*)(p.C + (size_t)m * p.ldc + n0) = o;
@@ -33,5 +35,6 @@ DEVI void nt_epilogue(const PlbGemmNT& p, f32x4 v, int m, int n0) {
       g.y = pack_bf2(gelu_new_f(bf_lo(o.y)), gelu_new_f(bf_hi(o.y)));
       *(uint2*)(p.C2 + (size_t)m * p.ldc2 + n0) = g;
     }
+    return f32x4{bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};
   }
 }

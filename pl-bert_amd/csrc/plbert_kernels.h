@@ -29,8 +29,10 @@ typedef struct {
   bf16_t* C; int ldc;           // bf16 out (act==1: pre-activation u)
   bf16_t* C2; int ldc2;         // act==1: gelu_new(u)
   float* Cf; int ldcf;          // out_f32
+  float* colpart;               // big-tile kernels only, or null: [2*M/TM][N] partial column sums of the output
 } PlbGemmNT;
 int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream);
+int plb_gemm_nt_colpart_rows(int M, int N, int K);  // rows of colpart written for this shape (0: unsupported)
 
 // slab[split][N][K] = A[rows,N]^T · B[rows,K] over the split's rows; Mtot%64==0, rows_per_split%64==0,
 // Ncols (readable columns of A) %8==0, K%8==0.
