@@ -149,44 +149,63 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(PlbEmbed p, int P) {
 
 // ------------------------------------------------------------------------- LayerNorm(H) (A7/A8)
 // nn.LayerNorm over the last dim, biased variance, eps inside the sqrt. NCH = ceil(H/256).
+// A wave handles LN_R rows per iteration with all their loads issued before the first reduction:
+// the kernels are pure HBM streams and one row per wave (3 x 8 B per lane) left them latency-bound.
+constexpr int LN_R = 2;
+
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(PlbLayerNorm p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = p.H;
   const float invH = 1.0f / (float)H;
-  for (int t = blockIdx.x * 4 + wave; t < p.T; t += gridDim.x * 4) {
-    float x[NCH][4];
-    float s = 0.f;
+  float4 g[NCH], b[NCH];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (c < H) {
-        uint2 u = *(const uint2*)(p.x + (size_t)t * p.ldx + c);
-        x[i][0] = bf_lo(u.x); x[i][1] = bf_hi(u.x); x[i][2] = bf_lo(u.y); x[i][3] = bf_hi(u.y);
-      } else {
-        x[i][0] = x[i][1] = x[i][2] = x[i][3] = 0.f;
+  for (int i = 0; i < NCH; ++i) {
+    const int c = (lane + 64 * i) * 4;
+    g[i] = (c < H) ? *(const float4*)(p.gamma + c) : make_float4(0, 0, 0, 0);
+    b[i] = (c < H) ? *(const float4*)(p.beta + c) : make_float4(0, 0, 0, 0);
+  }
+  for (int t0 = (blockIdx.x * 4 + wave) * LN_R; t0 < p.T; t0 += gridDim.x * 4 * LN_R) {
+    uint2 u[LN_R][NCH];
+#pragma unroll
+    for (int r = 0; r < LN_R; ++r) {
+      const int t = (t0 + r < p.T) ? t0 + r : p.T - 1;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        u[r][i] = (c < H) ? *(const uint2*)(p.x + (size_t)t * p.ldx + c) : make_uint2(0, 0);
       }
-      s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
     }
-    const float mean = wave_sum(s) * invH;
-    float vs = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = (lane + 64 * i) * 4;
+    for (int r = 0; r < LN_R; ++r) {
+      const int t = t0 + r;
+      float x[NCH][4], s = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { x[i][j] = (c < H) ? x[i][j] - mean : 0.f; vs += x[i][j] * x[i][j]; }
-    }
-    const float rstd = rsqrtf(wave_sum(vs) * invH + p.eps);
-    if (lane == 0 && p.mean) { p.mean[t] = mean; p.rstd[t] = rstd; }
+      for (int i = 0; i < NCH; ++i) {
+        x[i][0] = bf_lo(u[r][i].x); x[i][1] = bf_hi(u[r][i].x); x[i][2] = bf_lo(u[r][i].y); x[i][3] = bf_hi(u[r][i].y);
+        s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
+      }
+      const float mean = wave_sum(s) * invH;
+      float vs = 0.f;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (c < H) {
-        float4 g = *(const float4*)(p.gamma + c), b = *(const float4*)(p.beta + c);
-        uint2 o;
-        o.x = pack_bf2(x[i][0] * rstd * g.x + b.x, x[i][1] * rstd * g.y + b.y);
-        o.y = pack_bf2(x[i][2] * rstd * g.z + b.z, x[i][3] * rstd * g.w + b.w);
-        *(uint2*)(p.y + (size_t)t * p.ldy + c) = o;
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x[i][j] = (c < H) ? x[i][j] - mean : 0.f; vs += x[i][j] * x[i][j]; }
+      }
+      const float rstd = rsqrtf(wave_sum(vs) * invH + p.eps);
+      if (t < p.T) {
+        if (lane == 0 && p.mean) { p.mean[t] = mean; p.rstd[t] = rstd; }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+          const int c = (lane + 64 * i) * 4;
+          if (c < H) {
+            uint2 o;
+            o.x = pack_bf2(x[i][0] * rstd * g[i].x + b[i].x, x[i][1] * rstd * g[i].y + b[i].y);
+            o.y = pack_bf2(x[i][2] * rstd * g[i].z + b[i].z, x[i][3] * rstd * g[i].w + b[i].w);
+            *(uint2*)(p.y + (size_t)t * p.ldy + c) = o;
+          }
+        }
       }
     }
   }
@@ -207,37 +226,49 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
   }
-  for (int t = blockIdx.x * 4 + wave; t < p.T; t += gridDim.x * 4) {
-    const float mean = p.mean[t], rstd = p.rstd[t];
-    float xh[NCH][4], dxh[NCH][4];
-    float s1 = 0.f, s2 = 0.f;
+  for (int t0 = (blockIdx.x * 4 + wave) * LN_R; t0 < p.T; t0 += gridDim.x * 4 * LN_R) {
+    uint2 ux[LN_R][NCH], ud[LN_R][NCH];
+    float mean[LN_R], rstd[LN_R];
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      float xv[4] = {0, 0, 0, 0}, dyv[4] = {0, 0, 0, 0};
-      if (c < H) {
-        uint2 u = *(const uint2*)(p.x + (size_t)t * p.ldx + c);
-        uint2 d = *(const uint2*)(p.dy + (size_t)t * p.lddy + c);
-        xv[0] = bf_lo(u.x); xv[1] = bf_hi(u.x); xv[2] = bf_lo(u.y); xv[3] = bf_hi(u.y);
-        dyv[0] = bf_lo(d.x); dyv[1] = bf_hi(d.x); dyv[2] = bf_lo(d.y); dyv[3] = bf_hi(d.y);
-      }
+    for (int r = 0; r < LN_R; ++r) {
+      const int t = (t0 + r < p.T) ? t0 + r : p.T - 1;
+      mean[r] = p.mean[t]; rstd[r] = p.rstd[t];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        xh[i][j] = (c < H) ? (xv[j] - mean) * rstd : 0.f;
-        dxh[i][j] = dyv[j] * gm[i][j];
-        s1 += dxh[i][j]; s2 += dxh[i][j] * xh[i][j];
-        dg[i][j] += dyv[j] * xh[i][j]; db[i][j] += dyv[j];
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        ux[r][i] = (c < H) ? *(const uint2*)(p.x + (size_t)t * p.ldx + c) : make_uint2(0, 0);
+        ud[r][i] = (c < H) ? *(const uint2*)(p.dy + (size_t)t * p.lddy + c) : make_uint2(0, 0);
       }
     }
-    s1 = wave_sum(s1) * invH; s2 = wave_sum(s2) * invH;
 #pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-      const int c = (lane + 64 * i) * 4;
-      if (c < H) {
-        uint2 o;
-        o.x = pack_bf2(rstd * (dxh[i][0] - s1 - xh[i][0] * s2), rstd * (dxh[i][1] - s1 - xh[i][1] * s2));
-        o.y = pack_bf2(rstd * (dxh[i][2] - s1 - xh[i][2] * s2), rstd * (dxh[i][3] - s1 - xh[i][3] * s2));
-        *(uint2*)(p.dx + (size_t)t * p.lddx + c) = o;
+    for (int r = 0; r < LN_R; ++r) {
+      const int t = t0 + r;
+      if (t >= p.T) continue;  // wave-uniform
+      float xh[NCH][4], dxh[NCH][4];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        const float xv[4] = {bf_lo(ux[r][i].x), bf_hi(ux[r][i].x), bf_lo(ux[r][i].y), bf_hi(ux[r][i].y)};
+        const float dyv[4] = {bf_lo(ud[r][i].x), bf_hi(ud[r][i].x), bf_lo(ud[r][i].y), bf_hi(ud[r][i].y)};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          xh[i][j] = (c < H) ? (xv[j] - mean[r]) * rstd[r] : 0.f;
+          dxh[i][j] = dyv[j] * gm[i][j];
+          s1 += dxh[i][j]; s2 += dxh[i][j] * xh[i][j];
+          dg[i][j] += dyv[j] * xh[i][j]; db[i][j] += dyv[j];
+        }
+      }
+      s1 = wave_sum(s1) * invH; s2 = wave_sum(s2) * invH;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + 64 * i) * 4;
+        if (c < H) {
+          uint2 o;
+          o.x = pack_bf2(rstd[r] * (dxh[i][0] - s1 - xh[i][0] * s2), rstd[r] * (dxh[i][1] - s1 - xh[i][1] * s2));
+          o.y = pack_bf2(rstd[r] * (dxh[i][2] - s1 - xh[i][2] * s2), rstd[r] * (dxh[i][3] - s1 - xh[i][3] * s2));
+          *(uint2*)(p.dx + (size_t)t * p.lddx + c) = o;
+        }
       }
     }
   }
@@ -523,7 +554,7 @@ extern "C" int plb_launch_embed_bwd(const PlbEmbed* p, hipStream_t stream) {
 }
 extern "C" int plb_launch_ln_fwd(const PlbLayerNorm* p, hipStream_t stream) {
   if (p->H % 4 || p->H > 1024 || p->T <= 0) return 1;
-  int blocks = (p->T + 3) / 4; if (blocks > 4096) blocks = 4096;
+  int blocks = (p->T + 4 * LN_R - 1) / (4 * LN_R); if (blocks > 4096) blocks = 4096;
   ProfScope ps(PLB_K_LN_FWD, stream, 0, (double)p->T * (4.0 * p->H + 8));
   const int nch = (p->H + 255) / 256;
   switch (nch) {

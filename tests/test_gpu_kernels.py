@@ -60,6 +60,29 @@ def test_gemm_nt_big_tiles(tile, M, N, K):
     assert rel_l2(g.float(), gelu_new(u.float())) < 5e-3
 
 
+def test_big_gemm_race_screen():
+    """The multi-phase kernels hand LDS slots between DMA and readers by counted waits and barriers: a
+    mistake there shows as rare wrong tiles. Repeat launches must be bitwise identical and correct."""
+    L = _lib.lib()
+    for tile, (M, N, K) in ((256, (2048, 768, 2304)), (384, (2048, 2304, 768)), (256, (4096, 2048, 768))):
+        A, Bw = randbf(M, K, seed=41), randbf(N, K, scale=0.05, seed=42)
+        ref = A.float() @ Bw.float().T
+        try:
+            L.plb_set_gemm_nt_tile(tile)
+            first, _ = gemm_nt(A, Bw, N)
+            assert rel_l2(first.float(), ref) < 4e-3
+            for _ in range(25):
+                again, _ = gemm_nt(A, Bw, N)
+                assert torch.equal(again, first)
+        finally:
+            L.plb_set_gemm_nt_tile(0)
+    A, Bm = randbf(8192, 768, seed=43), randbf(8192, 512, seed=44)
+    first = gemm_tn(A, Bm, 768, 8, 1024, big=True)
+    assert rel_l2(first, A.float().T @ Bm.float()) < 1e-5
+    for _ in range(25):
+        assert torch.equal(gemm_tn(A, Bm, 768, 8, 1024, big=True), first)
+
+
 def test_gemm_nt_gelu_epilogues():
     M, N, K = 256, 256, 128
     A, Bw = randbf(M, K, seed=4), randbf(N, K, scale=0.2, seed=5)
