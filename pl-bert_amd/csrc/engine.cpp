@@ -105,7 +105,12 @@ struct PlbEngine {
   int64_t o_dqkv, o_dpre1, o_du, o_dpre2;
   int64_t o_dy0, o_dy1, o_da, o_dctx, o_de;
   int64_t o_hm, o_logm, o_dlog, o_dhm, o_rows, o_tgt, o_w, o_lrows;
-  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_logfull, o_dxe, o_ducol;
+  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_logfull, o_dxe, o_ducol, o_slab2, o_scratch2;
+  int64_t slab2_floats;
+  // side stream: the tail of the backward (embedding chain, bias / LayerNorm column sums) runs beside the
+  // four large weight-gradient GEMMs
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int64_t slab_floats;
   int64_t ws_bytes;
   int ln_blocks, emb_blocks;
@@ -252,12 +257,25 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   e->o_dxe = cv.take(Tp * E * 4);
   e->o_ducol = cv.take(L * (2 * Tp / 128) * I * 4);  // column-sum partials of dU from the GEMM epilogue
   e->o_scratch = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);  // colsum partials: up to 512 row splits
+  e->o_scratch2 = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);
+  {
+    int rps;
+    const int s2 = tn_splits(Tp, (int)H, (int)E, &rps);
+    e->slab2_floats = (int64_t)s2 * H * E;
+    e->o_slab2 = cv.take(e->slab2_floats * 4);
+  }
   e->ws_bytes = cv.off;
   *out = e;
   return 0;
 }
 
-extern "C" void plb_destroy(PlbEngine* e) { delete e; }
+extern "C" void plb_destroy(PlbEngine* e) {
+  if (!e) return;
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->side) (void)hipStreamDestroy(e->side);
+  delete e;
+}
 
 extern "C" int plb_param_layout(const PlbEngine* e, int64_t* offsets, int64_t* sizes, int64_t* total, int64_t* trainable) {
   if (!e) return fail("plb_param_layout: null engine");
@@ -280,6 +298,14 @@ extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_av
   if ((uintptr_t)workspace & 255) return fail("plb_bind: workspace must be 256-byte aligned");
   e->params = params; e->grads = grads; e->m = exp_avg; e->v = exp_avg_sq;
   e->ws = (char*)workspace;
+  if (!e->side && grads) {  // created once, outside any launch sequence (a step may be graph-captured)
+    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side = nullptr;
+    if (e->side && (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)) {
+      (void)hipStreamDestroy(e->side);
+      e->side = nullptr;
+    }
+  }
   return 0;
 }
 
@@ -423,13 +449,13 @@ extern "C" int plb_forward(PlbEngine* e, const int64_t* ids, const int32_t* leng
 
 // dW[N,K] = A^T B over Mtot rows -> grads[which] (overwrite)
 static int weight_grad(PlbEngine* e, const bf16_t* A, int lda, int Ncols, const bf16_t* Bm, int ldb, int64_t Mtot, int N,
-                       int K, float* out, hipStream_t s) {
+                       int K, float* out, hipStream_t s, bool side_slab = false) {
   PlbGemmTN t;
   memset(&t, 0, sizeof(t));
   t.A = A; t.lda = lda; t.Ncols = Ncols; t.B = Bm; t.ldb = ldb; t.Mtot = (int)Mtot; t.N = N; t.K = K;
   t.splits = tn_splits(Mtot, N, K, &t.rows_per_split);
-  if ((int64_t)t.splits * N * K > e->slab_floats) return fail("weight_grad: slab too small");
-  t.slab = e->at<float>(e->o_slab);
+  if ((int64_t)t.splits * N * K > (side_slab ? e->slab2_floats : e->slab_floats)) return fail("weight_grad: slab too small");
+  t.slab = e->at<float>(side_slab ? e->o_slab2 : e->o_slab);
   if (N == Ncols && tn_big(Mtot, Ncols, K)) {
     const int tok = plb_prof_begin(PLB_K_GEMM_TN, s, 2.0 * (double)Mtot * N * K, 0.0);
     TRY(plb_launch_gemm_tn_big(&t, s));
@@ -550,16 +576,29 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
     bf16_t* tmp = dy; dy = dy_other; dy_other = tmp;
   }
 
-  // ---- embeddings ------------------------------------------------------------------------------------------
+  // ---- tail of the backward on two streams --------------------------------------------------------------------
+  // main: the four large token-major weight-gradient GEMMs (MFMA-bound, ~2 ms at config A).
+  // side: everything else that only needs finished gradients — embedding chain, bias and LayerNorm-affine
+  //       column sums (HBM-bound, ~0.8 ms) — with its own slab / scratch so nothing is shared.
+  hipStream_t s2 = s;
+  float* scratch2 = scratch;
+  if (e->side) {
+    s2 = e->side;
+    scratch2 = e->at<float>(e->o_scratch2);
+    HIPTRY(hipEventRecord(e->ev_fork, s));
+    HIPTRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
+  }
+  const int64_t Mtot = (int64_t)L * Tp;
+  // side stream -------------------------------------------------------------------------------------------------------
   bf16_t* evec = e->at<bf16_t>(e->o_e);
   bf16_t* de = e->at<bf16_t>(e->o_de);
   memset(&g, 0, sizeof(g));
   g.A = dy; g.lda = H; g.B = e->at<bf16_t>(e->o_winT); g.ldb = H; g.M = (int)Tp; g.N = E; g.K = H; g.Mstore = (int)Tp;
   g.C = de; g.ldc = E;
-  TRY(plb_launch_gemm_nt(&g, 0, 0, s));
-  if (weight_grad(e, dy, H, H, evec, E, Tp, H, E, e->grd(PLB_MAP_W), s)) return 1;
-  TRY(plb_launch_colsum(dy, 1, (size_t)Tp, H, H, e->grd(PLB_MAP_B), H, 0, scratch, 128, s));
-  HIPTRY(hipMemsetAsync(e->grd(PLB_TYPE_EMB), 0, (size_t)e->psize[PLB_TYPE_EMB] * 4, s));
+  TRY(plb_launch_gemm_nt(&g, 0, 0, s2));
+  if (weight_grad(e, dy, H, H, evec, E, Tp, H, E, e->grd(PLB_MAP_W), s2, e->side != nullptr)) return 1;
+  TRY(plb_launch_colsum(dy, 1, (size_t)Tp, H, H, e->grd(PLB_MAP_B), H, 0, scratch2, 128, s2));
+  HIPTRY(hipMemsetAsync(e->grd(PLB_TYPE_EMB), 0, (size_t)e->psize[PLB_TYPE_EMB] * 4, s2));
   PlbEmbed em;
   memset(&em, 0, sizeof(em));
   em.ids = masked_ids; em.T = T; em.S = S; em.E = E; em.V = e->V;
@@ -568,28 +607,30 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   em.dout = de; em.lddo = E; em.dword = e->grd(PLB_WORD_EMB); em.dpos = e->grd(PLB_POS_EMB);
   em.dx = e->at<float>(e->o_dxe);
   em.partials = e->at<float>(e->o_parte); em.nblocks = e->emb_blocks;
-  TRY(plb_launch_embed_bwd(&em, s));
-  TRY(plb_launch_embed_scatter(&em, e->P, s));
-  TRY(plb_launch_colsum(em.partials, 0, (size_t)e->emb_blocks, 2 * E, 2 * E, e->grd(PLB_EMB_LN_W), 2 * E, 0, scratch, 1, s));
+  TRY(plb_launch_embed_bwd(&em, s2));
+  TRY(plb_launch_embed_scatter(&em, e->P, s2));
+  TRY(plb_launch_colsum(em.partials, 0, (size_t)e->emb_blocks, 2 * E, 2 * E, e->grd(PLB_EMB_LN_W), 2 * E, 0, scratch2, 1, s2));
   // token_type row 0 receives every token's gradient = the column sums of dpos
-  TRY(plb_launch_colsum(e->grd(PLB_POS_EMB), 0, (size_t)e->P, E, E, e->grd(PLB_TYPE_EMB), E, 0, scratch, 1, s));
-
-  // ---- shared-layer weight gradients: one token-major GEMM per weight over all L applications -----
-  const int64_t Mtot = (int64_t)L * Tp;
+  TRY(plb_launch_colsum(e->grd(PLB_POS_EMB), 0, (size_t)e->P, E, E, e->grd(PLB_TYPE_EMB), E, 0, scratch2, 1, s2));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dqkv), 1, (size_t)Mtot, 3 * H, 3 * H, e->grd(PLB_Q_B), 3 * H, 0, scratch2, 64, s2));
+  if (du_rows > 0)
+    TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 16, s2));
+  else
+    TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 64, s2));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre1), 1, (size_t)Mtot, H, H, e->grd(PLB_DENSE_B), H, 0, scratch2, 128, s2));
+  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre2), 1, (size_t)Mtot, H, H, e->grd(PLB_FFNO_B), H, 0, scratch2, 128, s2));
+  const size_t prow = (size_t)L * e->ln_blocks;  // LayerNorm-backward partials [L*blocks][2H]: dgamma | dbeta
+  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 2 * H, 2 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch2, 16, s2));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 2 * H, 2 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch2, 16, s2));
+  // main stream: shared-layer weight gradients, one token-major GEMM per weight over all L applications ------------
   if (weight_grad(e, e->at<bf16_t>(e->o_dqkv), 3 * H, 3 * H, e->at<bf16_t>(e->o_x), H, Mtot, 3 * H, H, e->grd(PLB_Q_W), s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dqkv), 1, (size_t)Mtot, 3 * H, 3 * H, e->grd(PLB_Q_B), 3 * H, 0, scratch, 64, s));
-  if (du_rows > 0)
-    TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 16, s));
-  else
-    TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch, 64, s));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre1), 1, (size_t)Mtot, H, H, e->grd(PLB_DENSE_B), H, 0, scratch, 128, s));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre2), 1, (size_t)Mtot, H, H, e->grd(PLB_FFNO_B), H, 0, scratch, 128, s));
-  const size_t prow = (size_t)L * e->ln_blocks;  // LayerNorm-backward partials [L*blocks][2H]: dgamma | dbeta
-  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 2 * H, 2 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch, 16, s));
-  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 2 * H, 2 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch, 16, s));
+  if (e->side) {
+    HIPTRY(hipEventRecord(e->ev_join, s2));
+    HIPTRY(hipStreamWaitEvent(s, e->ev_join, 0));
+  }
   return 0;
 }
 
