@@ -31,22 +31,21 @@ DEVI float wave_max(float v) {
   return v;
 }
 
-// gelu_new (HF activations.py:59-66): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-DEVI float tanh_fast(float z) {
-  // tanh(z) = 1 - 2 / (exp(2z) + 1); exp via exp2. Saturates cleanly for |z| large.
-  float e = __builtin_amdgcn_exp2f(z * 2.885390081777927f);  // 2*log2(e)
-  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+// gelu_new (HF activations.py:59-66): 0.5 x (1 + tanh(z)), z = sqrt(2/pi) (x + 0.044715 x^3)
+//   = x * sigmoid(2z) = x / (1 + exp2(x * (K1 + K3 x^2))),  K1 = -2 sqrt(2/pi) log2(e), K3 = 0.044715 K1.
+// One v_exp + one v_rcp + 5 plain VALU per value (the GEMM epilogues evaluate it 128x per lane per tile).
+// Saturates cleanly: exp2 -> inf gives rcp -> 0 (x -> -inf), exp2 -> 0 gives s = 1 (x -> +inf).
+DEVI float gelu_sigmoid(float x, float x2) {
+  const float e = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x2, -0.10294324f, -2.3022082f));
+  return __builtin_amdgcn_rcpf(1.0f + e);
 }
-DEVI float gelu_new_f(float x) {
-  const float c = 0.7978845608028654f;
-  float t = tanh_fast(c * (x + 0.044715f * x * x * x));
-  return 0.5f * x * (1.0f + t);
-}
+DEVI float gelu_new_f(float x) { return x * gelu_sigmoid(x, x * x); }
+// d/dx = s + x s (1 - s) d(2z)/dx,  d(2z)/dx = 2 sqrt(2/pi) (1 + 3*0.044715 x^2)
 DEVI float gelu_new_grad_f(float x) {
-  const float c = 0.7978845608028654f;
-  float x2 = x * x;
-  float t = tanh_fast(c * (x + 0.044715f * x * x2));
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * c * (1.0f + 0.134145f * x2);
+  const float x2 = x * x;
+  const float s = gelu_sigmoid(x, x2);
+  const float w = x * __builtin_fmaf(x2, 0.21406444f, 1.5957691f);
+  return __builtin_fmaf(s, w * (1.0f - s), s);
 }
 
 // ds_read_b64_tr_b16: per 16-lane group a 4-row x 16-col block of 16-bit elements, delivered
