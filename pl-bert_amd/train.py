@@ -206,12 +206,46 @@ class AdamW:
         self.engine.adamw_step(self.step_count, d["lr"], d["betas"], d["eps"], d["weight_decay"], self.grad_scale)
 
     def state_dict(self):
+        """torch.optim.AdamW layout ({'state': {index: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}) with
+        parameter indices in ``model.parameters()`` order, so the 'optimizer' entry of a checkpoint
+        (train.py:417-421) can be loaded by either implementation. Parameters that never received a
+        gradient (the pooler) have no state, as in torch."""
         e = self.engine
-        return {"step": self.step_count, "exp_avg": e.exp_avg[: e.trainable].clone(),
-                "exp_avg_sq": e.exp_avg_sq[: e.trainable].clone(), "defaults": dict(self.defaults)}
+        d = self.defaults
+        state = {}
+        if self.step_count > 0:
+            for i, n in enumerate(self._names):
+                off, size, shp = e.layout[n]
+                if off + size <= e.trainable:
+                    state[i] = {"step": torch.tensor(float(self.step_count)),
+                                "exp_avg": e.exp_avg[off:off + size].view(shp).clone(),
+                                "exp_avg_sq": e.exp_avg_sq[off:off + size].view(shp).clone()}
+        group = {"lr": d["lr"], "betas": tuple(d["betas"]), "eps": d["eps"], "weight_decay": d["weight_decay"],
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": True, "params": list(range(len(self.param_list)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
         e = self.engine
-        self.step_count = int(sd["step"])
+        if "param_groups" in sd:
+            g = sd["param_groups"][0]
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in g:
+                    self.defaults[k] = tuple(g[k]) if k == "betas" else g[k]
+            steps = set()
+            e.exp_avg.zero_()
+            e.exp_avg_sq.zero_()
+            for i, st in sd["state"].items():
+                off, size, shp = e.layout[self._names[int(i)]]
+                if off + size > e.trainable:
+                    continue
+                e.exp_avg[off:off + size].view(shp).copy_(st["exp_avg"])
+                e.exp_avg_sq[off:off + size].view(shp).copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused AdamW keeps one step")
+            self.step_count = steps.pop() if steps else 0
+            return
+        self.step_count = int(sd["step"])  # compact form written by early versions of this class
         e.exp_avg[: e.trainable].copy_(sd["exp_avg"])
         e.exp_avg_sq[: e.trainable].copy_(sd["exp_avg_sq"])

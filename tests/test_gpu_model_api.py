@@ -87,6 +87,44 @@ def test_reference_loop_body_runs_unchanged():
     assert opt2.step_count == opt.step_count
 
 
+def test_checkpoint_files_are_interchangeable_with_torch(tmp_path):
+    """step_N.pth layout {'net','step','epoch','optimizer'} (train.py:412-425): written here, the optimizer
+    entry loads into torch.optim.AdamW over same-shaped parameters; a file with DDP 'module.' prefixes and a
+    torch AdamW state loads back here and training resumes on the golden loss trajectory."""
+    g = load_golden("small_h128")
+    m, pcfg, sd = _make(g)
+    opt = plbert_amd.AdamW(m.parameters(), lr=1e-3, model=m)
+    batch = (torch.from_numpy(g["labels"]), torch.from_numpy(g["masked"]), [int(x) for x in g["lengths"]],
+             [list(map(int, x)) for x in g["index"]])
+    losses = []
+    for step in range(2):
+        loss = plbert_amd.process_batch(m, batch)
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss.item()))
+    path = plbert_amd.save_checkpoint(m, opt, 2, str(tmp_path), None, current_epoch=1)
+    assert plbert_amd.find_latest_checkpoint(str(tmp_path)) == (True, 2)
+    ck = torch.load(path, weights_only=False)
+    assert set(ck.keys()) == {"net", "step", "epoch", "optimizer"} and ck["step"] == 2 and ck["epoch"] == 1
+    # torch's optimizer accepts the saved state for parameters of the same shapes / order
+    shadow = [torch.nn.Parameter(p.detach().cpu().clone()) for p in m.parameters()]
+    topt = torch.optim.AdamW(shadow, lr=1e-3)
+    topt.load_state_dict(ck["optimizer"])
+    names = [n for n, _ in m.named_parameters()]
+    i_head = names.index("phoneme_predictor.weight")
+    assert torch.allclose(topt.state[shadow[i_head]]["exp_avg"], m.engine.view("phoneme_predictor.weight", of=m.engine.exp_avg).cpu())
+    assert shadow[names.index("encoder.pooler.weight")] not in topt.state      # never stepped
+    # a reference-style file (DDP prefixes, torch optimizer state) resumes here
+    ck2 = {"net": {"module." + k: v for k, v in ck["net"].items()}, "step": 2, "epoch": 1, "optimizer": topt.state_dict()}
+    torch.save(ck2, str(tmp_path / "step_7.pth"))
+    assert plbert_amd.find_latest_checkpoint(str(tmp_path)) == (True, 7)
+    m2, _, _ = _make(g)
+    opt_b = plbert_amd.AdamW(m2.parameters(), lr=1e-3, model=m2)
+    plbert_amd.load_checkpoint(m2, opt_b, str(tmp_path / "step_7.pth"), None)
+    assert opt_b.step_count == 2
+    loss3 = plbert_amd.process_batch(m2, batch)
+    assert abs(float(loss3.item()) - float(g["losses"][2])) / float(g["losses"][2]) < 2e-3
+
+
 def test_standalone_encoder_loads_stripped_checkpoint():
     """README.md:49-66 consumer: strip 'module.' and 'encoder.' and load into AlbertModel."""
     g = load_golden("small_h128")
