@@ -123,6 +123,19 @@ int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* lab
 int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float grad_scale, void* stream);
 
+/* Device-side fast mode of the word-level masking that MaskedPhonemeDataset does on the host
+ * (dataloader.py:83-108): same decision tree and probabilities (select a word with word_pred_prob;
+ * then mask with phoneme_mask_prob / replace from the sample's own phonemes with replace_prob / keep),
+ * separators never masked or indexed, but counter-based Philox randomness keyed by (seed, step, sample,
+ * word) instead of the reference's global NumPy/Python streams — distribution-matched, NOT bit-exact
+ * (the bit-exact path is the host one in pl-bert_amd/data.py). Needs no engine.
+ * labels int64 [B,S] (separator id sep_id between words, positions >= lengths[b] ignored); outputs:
+ * masked int64 [B,S], idx_offsets int32 [B+1], idx_flat int32 [up to B*S], scratch int32 [B + B*S].
+ * S <= 512, B <= 1024. The total count is idx_offsets[B] (read it back before plb_loss_fwd_bwd). */
+int plb_mask_batch(const int64_t* labels, const int32_t* lengths, int32_t B, int32_t S, uint64_t seed, uint32_t step,
+                   float word_pred_prob, float phoneme_mask_prob, float replace_prob, int32_t mask_id, int32_t sep_id,
+                   int64_t* masked, int32_t* idx_offsets, int32_t* idx_flat, int32_t* scratch, void* stream);
+
 /* Measurement aid (no reference counterpart; the reference has no profiling): when
  * enabled, every kernel launch is bracketed by two HIP events on its stream. plb_profile_read waits
  * for them and returns, per kernel class, total milliseconds, launch count and the algorithmic

@@ -13,7 +13,8 @@ def __getattr__(name):
     if name in ("AlbertModel", "PhonemeOnlyModel", "MultiTaskModel", "BaseModelOutputWithPooling"):
         from . import model
         return getattr(model, name)
-    if name in ("PLBertTrainer", "process_batch", "AdamW", "StagedBatch", "stage_reference_batch", "validate_batch"):
+    if name in ("PLBertTrainer", "process_batch", "AdamW", "StagedBatch", "stage_reference_batch", "validate_batch",
+                "device_mask_batch"):
         from . import train
         return getattr(train, name)
     if name in ("save_checkpoint", "load_checkpoint", "find_latest_checkpoint"):
@@ -27,7 +28,7 @@ def __getattr__(name):
 
 __all__ = [
     "AlbertModel", "PhonemeOnlyModel", "MultiTaskModel", "PLBertTrainer", "process_batch", "AdamW", "HipEngine",
-    "save_checkpoint", "load_checkpoint", "find_latest_checkpoint",
+    "save_checkpoint", "load_checkpoint", "find_latest_checkpoint", "device_mask_batch",
     "AlbertConfig", "albert_config_from_yaml", "load_config",
     "CharacterIndexer", "symbols", "PAD_ID", "MASK_ID", "SEPARATOR_ID", "UNKNOWN_ID",
     "param_shapes", "deterministic_state_dict", "reference_init_state_dict",

@@ -51,7 +51,7 @@ PLB_NPARAM = len(PLB_PARAM_NAMES)
 # every symbol include/plbert.h declares (tests check the library exports all of them)
 PUBLIC_SYMBOLS = [
     "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
-    "plb_sync_weights", "plb_forward", "plb_loss_fwd_bwd", "plb_adamw_step",
+    "plb_sync_weights", "plb_forward", "plb_loss_fwd_bwd", "plb_adamw_step", "plb_mask_batch",
     "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
 ]
 
@@ -144,6 +144,8 @@ def lib():
     L.plb_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.plb_adamw_step.restype = C.c_int
     L.plb_adamw_step.argtypes = [vp, f32, f32, f32, f32, f32, i32, f32, vp]
+    L.plb_mask_batch.restype = C.c_int
+    L.plb_mask_batch.argtypes = [vp, vp, i32, i32, C.c_uint64, C.c_uint32, f32, f32, f32, i32, i32, vp, vp, vp, vp, vp]
     L.plb_profile_enable.restype = None
     L.plb_profile_enable.argtypes = [C.c_int]
     L.plb_profile_num_classes.restype = C.c_int

@@ -634,6 +634,22 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   return 0;
 }
 
+extern "C" int plb_mask_batch(const int64_t* labels, const int32_t* lengths, int32_t B, int32_t S, uint64_t seed,
+                              uint32_t step, float word_pred_prob, float phoneme_mask_prob, float replace_prob,
+                              int32_t mask_id, int32_t sep_id, int64_t* masked, int32_t* idx_offsets, int32_t* idx_flat,
+                              int32_t* scratch, void* stream) {
+  if (!labels || !masked || !idx_offsets || !idx_flat || !scratch) return fail("plb_mask_batch: null argument");
+  if (S < 1 || S > 512 || B < 1 || B > 1024) return fail("plb_mask_batch: needs 1 <= S <= 512, 1 <= B <= 1024");
+  PlbMask m;
+  memset(&m, 0, sizeof(m));
+  m.labels = labels; m.lengths = lengths; m.B = B; m.S = S; m.seed = seed; m.step = step;
+  m.word_pred_prob = word_pred_prob; m.mask_prob = phoneme_mask_prob; m.replace_prob = replace_prob;
+  m.mask_id = mask_id; m.sep_id = sep_id;
+  m.masked = masked; m.counts = scratch; m.idx_padded = scratch + B; m.offsets = idx_offsets; m.flat = idx_flat;
+  TRY(plb_launch_mask(&m, (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, float eps, float weight_decay,
                               int32_t step, float grad_scale, void* stream) {
   if (!e || !e->ws || !e->grads || !e->m || !e->v) return fail("plb_adamw_step: optimizer buffers not bound");

@@ -118,6 +118,18 @@ int plb_launch_ce_fwd_bwd(const float* logits, int ldl, int V, const int32_t* tg
 // loss[0] = sum(loss_rows[0..n))  (single block, deterministic order)
 int plb_launch_sum_rows(const float* x, int n, float* out, hipStream_t stream);
 
+// Device-side word masking (mask.hip): labels [B,S] -> masked [B,S], counts [B], idx_padded [B,S],
+// then offsets [B+1] and flat (CSR of the modified positions).
+typedef struct {
+  const int64_t* labels; const int32_t* lengths;  // lengths may be null (= S)
+  int B, S;
+  uint64_t seed; uint32_t step;
+  float word_pred_prob, mask_prob, replace_prob;
+  int mask_id, sep_id;
+  int64_t* masked; int32_t *counts, *idx_padded, *offsets, *flat;
+} PlbMask;
+int plb_launch_mask(const PlbMask* p, hipStream_t stream);
+
 // AdamW (torch.optim.AdamW semantics) over a flat range; also refreshes the bf16 compute copy.
 int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, float lr, float beta1,
                      float beta2, float eps, float wd, int step, float grad_scale, hipStream_t stream);

@@ -149,6 +149,40 @@ def stage_reference_batch(engine, batch, validate=True):
                        int(off[-1]), int(lens.sum()))
 
 
+def device_mask_batch(labels, lengths=None, seed=1, step=0, word_pred_prob=0.15, phoneme_mask_prob=0.8, replace_prob=0.1,
+                      device=None):
+    """Fast mode of the masking path: word-level mask / replace / keep ON THE DEVICE
+    (plb_mask_batch). Same decision tree and probabilities as MaskedPhonemeDataset (dataloader.py:83-108),
+    Philox randomness keyed by (seed, step, sample, word): distribution-matched, not the reference's bit
+    stream. ``labels`` int64 [B,S] = unmasked phoneme ids with the separator 186 after each word, zero
+    padded; returns a StagedBatch (one small device->host read for the masked count)."""
+    import ctypes as C
+
+    from . import _lib
+    from .symbols import MASK_ID, SEPARATOR_ID
+
+    L = _lib.lib()
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    labels_t = torch.as_tensor(np.asarray(labels) if not torch.is_tensor(labels) else labels).to(dev, torch.int64).contiguous()
+    B, S = labels_t.shape
+    lengths_t = None
+    if lengths is not None:
+        lens = np.asarray(lengths, dtype=np.int32)
+        lengths_t = None if (lens == S).all() else torch.from_numpy(lens).to(dev)
+    masked = torch.empty_like(labels_t)
+    offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    flat = torch.empty(B * S, dtype=torch.int32, device=dev)
+    scratch = torch.empty(B + B * S, dtype=torch.int32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(L.plb_mask_batch(labels_t.data_ptr(), None if lengths_t is None else lengths_t.data_ptr(), B, S,
+                                int(seed), int(step), word_pred_prob, phoneme_mask_prob, replace_prob, MASK_ID,
+                                SEPARATOR_ID, masked.data_ptr(), offsets.data_ptr(), flat.data_ptr(), scratch.data_ptr(),
+                                stream), "plb_mask_batch")
+    n = int(offsets[B].item())
+    n_tokens = int(B * S if lengths is None else np.asarray(lengths).sum())
+    return StagedBatch(masked, labels_t, lengths_t, offsets, flat[:n], n, n_tokens)
+
+
 def process_batch(model, batch, criterion=None, accelerator=None):
     """train.py:381-390 — ``batch = (phoneme_labels, masked_phonemes, input_lengths, masked_indices)``.
     ``criterion`` / ``accelerator`` are accepted for signature compatibility: the loss is the
