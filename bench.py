@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--model", choices=["base", "large"], default="base",
+                    help="base = BASELINE configs[1] (hidden 768 / 12 layers, the bench line); large = configs[3] "
+                         "(hidden 1024 / 24 layers / 16 heads / FFN 4096, batch 16): utilisation report only")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the gradient all-reduce even at world size 1 "
                          "(rehearses the N>1 code path on a one-GPU box)")
@@ -98,8 +101,18 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
-    cfg = plbert_amd.AlbertConfig(vocab_size=len(plbert_amd.symbols), hidden_size=768, num_attention_heads=12,
-                                  intermediate_size=2048, max_position_embeddings=512, num_hidden_layers=12)
+    if args.model == "large":
+        cfg = plbert_amd.AlbertConfig(vocab_size=len(plbert_amd.symbols), hidden_size=1024, num_attention_heads=16,
+                                      intermediate_size=4096, max_position_embeddings=512, num_hidden_layers=24)
+        flop_per_token = 1_964_875_776
+        if args.batch == 32:
+            args.batch = 16
+        model_desc = "hidden 1024 / 24 shared layers / FFN 4096 / 16 heads"
+    else:
+        cfg = plbert_amd.AlbertConfig(vocab_size=len(plbert_amd.symbols), hidden_size=768, num_attention_heads=12,
+                                      intermediate_size=2048, max_position_embeddings=512, num_hidden_layers=12)
+        flop_per_token = FLOP_PER_TOKEN_STEP
+        model_desc = "hidden 768 / 12 shared layers / FFN 2048 / 12 heads"
     B, S = args.batch, args.seq
     trainer = PLBertTrainer(cfg, num_phonemes=len(plbert_amd.symbols), max_batch=B, max_seq=S, lr=7e-5,
                             device=f"cuda:{local_rank}", seed=0, force_collectives=args.force_dist)
@@ -145,7 +158,7 @@ def main():
                         "share_of_kernel_time": round(dom["ms"] / total_ms, 3),
                         "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in
                                                sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
-                        "step_mfma_frac": round(FLOP_PER_TOKEN_STEP * B * S / (total_ms / args.steps * 1e-3) / 1e12
+                        "step_mfma_frac": round(flop_per_token * B * S / (total_ms / args.steps * 1e-3) / 1e12
                                                 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
     cpu = None
@@ -159,10 +172,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"PL-BERT masked-phoneme training step (fwd+loss+bwd+allreduce+AdamW), ALBERT "
-                                   f"hidden 768 / 12 shared layers / FFN 2048 / 12 heads, seq_len {S}, batch {B} per GPU",
+                                   f"{model_desc}, seq_len {S}, batch {B} per GPU",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
             "step_loss": round(loss_val, 5),
-            "step_mfma_frac_wall": round(FLOP_PER_TOKEN_STEP * B * S / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "step_mfma_frac_wall": round(flop_per_token * B * S / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -171,6 +171,32 @@ def test_against_oracle_random_shapes():
         _grad_close(eng, k, want, 4e-2)
 
 
+def test_large_config_hidden1024_against_oracle():
+    """BASELINE.json configs[3] architecture (hidden 1024, 16 heads, FFN 4096 — heads/FFN assumed
+    ALBERT-large as SURVEY.md §8 does) at reduced depth/batch so the fp32 oracle finishes in seconds."""
+    ocfg = onp.Config(embedding_size=128, hidden_size=1024, num_attention_heads=16, intermediate_size=4096,
+                      num_hidden_layers=3)
+    pcfg = plbert_amd.AlbertConfig(vocab_size=188, embedding_size=128, hidden_size=1024, num_attention_heads=16,
+                                   intermediate_size=4096, num_hidden_layers=3)
+    sd = plbert_amd.deterministic_state_dict(pcfg, 188, seed=11)
+    labels, masked, lengths, idx = plbert_amd.synthetic_batch(2, 256, seed=77)
+    lengths = [256, 201]
+    idx = [idx[0], [i for i in idx[1] if i < 201]]
+    labels[1, 201:] = 0
+    masked[1, 201:] = 0
+    loss_ref, pred_ref, G = onp.loss_and_grads(ocfg, sd, masked, labels, lengths, idx)
+    eng = HipEngine(pcfg, 188, 0, max_batch=2, max_seq=256)
+    eng.load_state_dict(sd)
+    _, ph, _ = eng.forward(masked, np.asarray(lengths, np.int32))
+    v = np.arange(256)[None, :] < np.asarray(lengths)[:, None]
+    assert np.abs(ph.cpu().numpy()[v] - pred_ref[v]).max() < 3e-2
+    off, flat = plbert_amd.masked_indices_to_csr(idx)
+    loss = eng.loss_fwd_bwd(masked, labels, np.asarray(lengths, np.int32), off, flat, int(off[-1]))
+    assert abs(float(loss.item()) - float(loss_ref)) / float(loss_ref) < 1e-3
+    for k, want in G.items():
+        _grad_close(eng, k, want, 4e-2)
+
+
 def test_zero_masked_indices_gives_zero_loss_and_grads():
     g = load_golden("small_h128")
     eng, *_ = _engine(g)
