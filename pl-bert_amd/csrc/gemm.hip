@@ -222,14 +222,18 @@ extern "C" int plb_launch_gemm_nt_big(const PlbGemmNT* p, int tile, int act, int
 // big tiles; 128x384 moves 4/3 the operand bytes per flop of 256x256, hence the small handicap.
 static int pick_tile(const PlbGemmNT* p) {
   const bool ok256 = p->M % 256 == 0 && p->N % 256 == 0, ok384 = p->M % 128 == 0 && p->N % 384 == 0;
+  const bool ok1256 = p->M % 128 == 0 && p->N % 256 == 0;
   if (g_nt_tile == 128) return 128;
   if (g_nt_tile == 256) return ok256 ? 256 : 128;
   if (g_nt_tile == 384) return ok384 ? 384 : (ok256 ? 256 : 128);
+  if (g_nt_tile == 1256) return ok1256 ? 1256 : 128;
   if ((long)p->M * p->N < 256L * 256 * 64) return 128;  // small problems: more, smaller workgroups
-  double e256 = 0, e384 = 0;
+  double e256 = 0, e384 = 0, e1256 = 0;
   if (ok256) { const long t = (long)(p->M / 256) * (p->N / 256); e256 = (double)t / (double)(((t + 255) / 256) * 256); }
   if (ok384) { const long t = (long)(p->M / 128) * (p->N / 384); e384 = 0.95 * (double)t / (double)(((t + 255) / 256) * 256); }
-  if (e256 == 0 && e384 == 0) return 128;
+  if (ok1256) { const long t = (long)(p->M / 128) * (p->N / 256); e1256 = 0.85 * (double)t / (double)(((t + 255) / 256) * 256); }
+  if (e256 == 0 && e384 == 0 && e1256 == 0) return 128;
+  if (e1256 > e256 && e1256 > e384) return 1256;
   return e384 > e256 ? 384 : 256;
 }
 
@@ -239,7 +243,7 @@ extern "C" int plb_gemm_nt_colpart_rows(int M, int N, int K) {
   PlbGemmNT q;
   q.M = M; q.N = N; q.K = K;
   const int tile = pick_tile(&q);
-  return tile == 256 ? 2 * (M / 256) : tile == 384 ? 2 * (M / 128) : 0;
+  return tile == 256 ? 2 * (M / 256) : (tile == 384 || tile == 1256) ? 2 * (M / 128) : 0;
 }
 
 extern "C" int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {

@@ -37,10 +37,13 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 
-// NBH = number of B half-tiles per K-tile (2: 256x256 tile, 3: 128x384 tile); A halves = 4 - NBH.
-template <int NBH, int ACT, bool OUTF32>
+// V selects the tile: 2 -> 256x256 (2 A halves, 2 B halves), 3 -> 128x384 (1 A, 3 B), 1 -> 128x256 (1 A, 2 B;
+// three half-tiles per K-tile, two phases, two half-tiles in flight: for shapes where the larger tiles
+// would leave CUs idle, e.g. N = 1024 at M = 8192).
+template <int V, int ACT, bool OUTF32>
 __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
-  constexpr int NAH = 4 - NBH;
+  constexpr int NAH = (V == 2) ? 2 : 1;
+  constexpr int NBH = (V == 3) ? 3 : 2;
   constexpr int TM = NAH * 128, TN = NBH * 128;
   constexpr int SB = NAH;  // first B slot
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * HT];  // 128 KiB
@@ -132,16 +135,26 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
   } while (0)
+#define LANDED4(more)                                                     \
+  do {                                                                    \
+    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+  } while (0)
 
-  // ---- prologue: K-tile 0 complete + the first three half-tiles (in consumption order) of K-tile 1
-  if constexpr (NBH == 2) {
+  // ---- prologue: K-tile 0 complete + the first half-tiles (in consumption order) of K-tile 1
+  if constexpr (V == 1) {
+    STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0);
+    if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); }
+    LANDED4(nk > 1);
+  } else if constexpr (V == 2) {
     STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, NAH - 1, 0);
     if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
+    LANDED(nk > 1);
   } else {
     STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_B(0, NBH - 1, 0);
     if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
+    LANDED(nk > 1);
   }
-  LANDED(nk > 1);
   BARRIER();
   // Stagger: the second wave of every SIMD (waves 4-7 = wm 1) runs half a phase behind the first, so
   // one group's LDS reads overlap the other group's MFMAs. A phase is {DMA issue, fragment reads,
@@ -156,7 +169,16 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   for (int t = 0; t < nk; ++t) {
     const int b = t & 1;
     const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-    if constexpr (NBH == 2) {
+    if constexpr (V == 1) {
+      if (n1) STAGE_B(b ^ 1, 1, t + 1);
+      READ_B(b0f, b, 0);
+      READ_A(b, 0);
+      MFMA_PART(0, 0, b0f);
+      if (n2) { STAGE_A(b, 0, t + 2); STAGE_B(b, 0, t + 2); }
+      LANDED4(n2);
+      READ_B(b1f, b, 1);
+      MFMA_PART(0, 1, b1f);
+    } else if constexpr (V == 2) {
       if (n1) STAGE_A(b ^ 1, NAH - 1, t + 1);
       READ_B(b0f, b, 0);
       READ_A(b, 0);
@@ -192,6 +214,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #undef MFMA_Q
 #undef MFMA_PART
 #undef LANDED
+#undef LANDED4
 
   // ---- epilogue. Loads are batched per 16-row slab — all bias vectors once, then the residual / aux
   // segments of one slab together — so a slab costs ONE memory round trip instead of one per 16x16
@@ -281,20 +304,20 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   }
 }
 
-template <int NBH>
+template <int V>
 int launch_big(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {
-  constexpr int TM = (4 - NBH) * 128, TN = NBH * 128;
+  constexpr int TM = (V == 2 ? 2 : 1) * 128, TN = (V == 3 ? 3 : 2) * 128;
   if (p->M % TM || p->N % TN || p->K % 64 || p->M <= 0 || p->N <= 0 || p->K <= 0) return 1;
   dim3 grid((p->M / TM) * (p->N / TN)), block(512);
   if (out_f32) {
     if (act != 0) return 1;
-    hipLaunchKernelGGL((gemm_nt_big_kernel<NBH, 0, true>), grid, block, 0, stream, *p);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<V, 0, true>), grid, block, 0, stream, *p);
   } else if (act == 0) {
-    hipLaunchKernelGGL((gemm_nt_big_kernel<NBH, 0, false>), grid, block, 0, stream, *p);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<V, 0, false>), grid, block, 0, stream, *p);
   } else if (act == 1) {
-    hipLaunchKernelGGL((gemm_nt_big_kernel<NBH, 1, false>), grid, block, 0, stream, *p);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<V, 1, false>), grid, block, 0, stream, *p);
   } else if (act == 2) {
-    hipLaunchKernelGGL((gemm_nt_big_kernel<NBH, 2, false>), grid, block, 0, stream, *p);
+    hipLaunchKernelGGL((gemm_nt_big_kernel<V, 2, false>), grid, block, 0, stream, *p);
   } else {
     return 1;
   }
@@ -496,7 +519,8 @@ extern "C" int plb_launch_gemm_tn_big(const PlbGemmTN* p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-// tile = 256: 256x256 (M % 256, N % 256); tile = 384: 128x384 (M % 128, N % 384). K % 64 == 0.
+// tile = 256: 256x256 (M % 256, N % 256); 384: 128x384 (M % 128, N % 384); 1256: 128x256 (M % 128, N % 256).
 extern "C" int plb_launch_gemm_nt_big(const PlbGemmNT* p, int tile, int act, int out_f32, hipStream_t stream) {
-  return tile == 384 ? launch_big<3>(p, act, out_f32, stream) : launch_big<2>(p, act, out_f32, stream);
+  return tile == 384 ? launch_big<3>(p, act, out_f32, stream)
+         : tile == 1256 ? launch_big<1>(p, act, out_f32, stream) : launch_big<2>(p, act, out_f32, stream);
 }

@@ -39,7 +39,8 @@ def test_gemm_nt_bias_residual(M, N, K):
 
 
 @pytest.mark.parametrize("tile,M,N,K", [(256, 256, 256, 64), (256, 512, 768, 768), (256, 256, 512, 128), (256, 512, 256, 192),
-                                        (384, 128, 384, 64), (384, 384, 768, 768), (384, 256, 2304, 128), (384, 128, 384, 2048)])
+                                        (384, 128, 384, 64), (384, 384, 768, 768), (384, 256, 2304, 128), (384, 128, 384, 2048),
+                                        (1256, 128, 256, 64), (1256, 384, 1024, 128), (1256, 256, 512, 192), (1256, 128, 256, 1024)])
 def test_gemm_nt_big_tiles(tile, M, N, K):
     """256x256 / 128x384 multi-phase kernels: 1, 2, 3 and many K-tiles (prologue, steady state, drain)."""
     L = _lib.lib()
@@ -64,7 +65,8 @@ def test_big_gemm_race_screen():
     """The multi-phase kernels hand LDS slots between DMA and readers by counted waits and barriers: a
     mistake there shows as rare wrong tiles. Repeat launches must be bitwise identical and correct."""
     L = _lib.lib()
-    for tile, (M, N, K) in ((256, (2048, 768, 2304)), (384, (2048, 2304, 768)), (256, (4096, 2048, 768))):
+    for tile, (M, N, K) in ((256, (2048, 768, 2304)), (384, (2048, 2304, 768)), (256, (4096, 2048, 768)),
+                            (1256, (2048, 1024, 1024))):
         A, Bw = randbf(M, K, seed=41), randbf(N, K, scale=0.05, seed=42)
         ref = A.float() @ Bw.float().T
         try:
