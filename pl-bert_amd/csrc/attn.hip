@@ -88,11 +88,16 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
 __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(PlbAttn p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][64 * 64];  // [stage][K row | V tr] 32 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, hd = blockIdx.y;
+  // 1-D grid, XCD-aware: the q-tiles of one (batch, head) read the same K/V, so they get consecutive
+  // logical ids = the same XCD's L2 (block id % 8 labels the XCD; placement affects speed only)
+  const int QT = (p.S + 127) >> 7;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = logical % QT, bh = logical / QT;
+  const int hd = bh % p.NH, b = bh / p.NH;
   const int S = p.S, H = p.H;
   int len = p.lengths ? p.lengths[b] : S;
   len = len < 1 ? 1 : (len > S ? S : len);
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = bx * 128 + wave * 32;
   const size_t tok0 = (size_t)b * S;
   const bf16_t* qbase = p.qkv + hd * 64;
   const bf16_t* kbase = p.qkv + H + hd * 64;
@@ -207,11 +212,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(PlbAttn p) {
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][3][64 * 64];  // [stage][K row | K tr | V row] 48 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, hd = blockIdx.y;
+  // 1-D grid, XCD-aware: the q-tiles of one (batch, head) read the same K/V, so they get consecutive
+  // logical ids = the same XCD's L2 (block id % 8 labels the XCD; placement affects speed only)
+  const int QT = (p.S + 127) >> 7;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = logical % QT, bh = logical / QT;
+  const int hd = bh % p.NH, b = bh / p.NH;
   const int S = p.S, H = p.H;
   int len = p.lengths ? p.lengths[b] : S;
   len = len < 1 ? 1 : (len > S ? S : len);
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = bx * 128 + wave * 32;
   const size_t tok0 = (size_t)b * S;
   const bf16_t* kbase = p.qkv + H + hd * 64;
   const bf16_t* vbase = p.qkv + 2 * H + hd * 64;
@@ -317,11 +327,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][4][64 * 64];  // 64 KiB
   __shared__ __attribute__((aligned(16))) float sstat[2][2][64];       // [stage][lse*log2e | delta][q]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b = blockIdx.z, hd = blockIdx.y;
+  const int QT = (p.S + 127) >> 7;  // key tiles of one (batch, head) share Q / dO: same XCD
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = logical % QT, bh = logical / QT;
+  const int hd = bh % p.NH, b = bh / p.NH;
   const int S = p.S, H = p.H;
   int len = p.lengths ? p.lengths[b] : S;
   len = len < 1 ? 1 : (len > S ? S : len);
-  const int key0 = blockIdx.x * 128 + wave * 32;
+  const int key0 = bx * 128 + wave * 32;
   const size_t tok0 = (size_t)b * S;
   const int ld = p.ldqkv;
   const int lk = lane & 31, h = lane >> 5;
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   const float sl2 = p.scale * LOG2E;
 
   // queries past the length carry exactly zero dO in this model (no loss there), so tiles stop at len
-  const int nqt = (blockIdx.x * 128 < len) ? ((len + 63) >> 6) : 0;
+  const int nqt = (bx * 128 < len) ? ((len + 63) >> 6) : 0;
   const int sr = tid >> 3, sc = tid & 7;
   uint4 qr0, qr1, dr0, dr1;
   float st_l = 0.f, st_d = 0.f;
@@ -442,7 +455,7 @@ static int check_attn(const PlbAttn* p) {
 
 extern "C" int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream) {
   if (check_attn(p)) return 1;
-  dim3 grid((p->S + 127) / 128, p->NH, p->B), block(256);
+  dim3 grid(((p->S + 127) / 128) * p->NH * p->B), block(256);
   const double unit = (double)p->B * p->NH * (double)p->S * p->S * 64.0;
   const double io = 2.0 * p->B * p->S * (double)p->H;
   const int tok = plb_prof_begin(PLB_K_ATTN_FWD, stream, 4.0 * unit, 4.0 * io);
@@ -453,7 +466,7 @@ extern "C" int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream) {
 
 extern "C" int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream) {
   if (check_attn(p) || p->lddctx % 8 || p->lddqkv % 8) return 1;
-  dim3 grid((p->S + 127) / 128, p->NH, p->B), block(256);
+  dim3 grid(((p->S + 127) / 128) * p->NH * p->B), block(256);
   // algorithmic work of the backward = 4 products (dP, dQ, dV, dK); the S recomputation in each
   // kernel and the second dP are not credited
   const double unit = (double)p->B * p->NH * (double)p->S * p->S * 64.0;
