@@ -27,6 +27,8 @@
 namespace {
 
 constexpr int HT = 128 * 64;  // elements per half-tile (16 KiB)
+constexpr int RING = 10;      // half-tile slots of the LDS ring used by the NT kernel (160 KiB)
+DEVI int ring_slot(int x) { return x >= 2 * RING ? x - 2 * RING : (x >= RING ? x - RING : x); }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -45,8 +47,8 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   constexpr int NAH = (V == 2) ? 2 : 1;
   constexpr int NBH = (V == 3) ? 3 : 2;
   constexpr int TM = NAH * 128, TN = NBH * 128;
-  constexpr int SB = NAH;  // first B slot
-  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * HT];  // 128 KiB
+  constexpr int NH = NAH + NBH;  // half-tiles per K-tile, consumed in the order A0 B0 B1 [A1 | B2]
+  __shared__ __attribute__((aligned(16))) bf16_t smem[RING * HT];  // 160 KiB: the whole LDS of a CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = uw >> 2, wn = uw & 3;
@@ -66,19 +68,31 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   const bf16_t* gB1 = p.B + (size_t)(bn * TN + (2 * uw + 1) * 8 + drow) * p.ldb + ch1;
   const size_t hA = (size_t)128 * p.lda, hB = (size_t)128 * p.ldb;
   const int dst0 = (2 * uw) * 8 * 64, dst1 = (2 * uw + 1) * 8 * 64;
-#define STAGE_A(buf, h, kt)                                                                                   \
+#define STAGE_A(slot, h, kt)                                                                                  \
   do {                                                                                                        \
     __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (h) * hA + (size_t)(kt) * 64),                            \
-                                     (lptr_t)&smem[((buf) * 4 + (h)) * HT + dst0], 16, 0, 0);                 \
+                                     (lptr_t)&smem[(slot) * HT + dst0], 16, 0, 0);                            \
     __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (h) * hA + (size_t)(kt) * 64),                            \
-                                     (lptr_t)&smem[((buf) * 4 + (h)) * HT + dst1], 16, 0, 0);                 \
+                                     (lptr_t)&smem[(slot) * HT + dst1], 16, 0, 0);                            \
   } while (0)
-#define STAGE_B(buf, h, kt)                                                                                   \
+#define STAGE_B(slot, h, kt)                                                                                  \
   do {                                                                                                        \
     __builtin_amdgcn_global_load_lds((gptr_t)(gB0 + (h) * hB + (size_t)(kt) * 64),                            \
-                                     (lptr_t)&smem[((buf) * 4 + SB + (h)) * HT + dst0], 16, 0, 0);            \
+                                     (lptr_t)&smem[(slot) * HT + dst0], 16, 0, 0);                            \
     __builtin_amdgcn_global_load_lds((gptr_t)(gB1 + (h) * hB + (size_t)(kt) * 64),                            \
-                                     (lptr_t)&smem[((buf) * 4 + SB + (h)) * HT + dst1], 16, 0, 0);            \
+                                     (lptr_t)&smem[(slot) * HT + dst1], 16, 0, 0);                            \
+  } while (0)
+// half-tile i of a K-tile, in consumption order: A0, B0, B1, then A1 (256x256) or B2 (128x384)
+#define STAGE_I(i, slot, kt)                                              \
+  do {                                                                    \
+    if (V == 2 && (i) == 3) STAGE_A(slot, 1, kt);                         \
+    else if ((i) == 0) STAGE_A(slot, 0, kt);                              \
+    else STAGE_B(slot, (i) - 1, kt);                                      \
+  } while (0)
+// issue half-tile number NH*t + c of the stream (c is a literal), if it exists
+#define ISSUE(c)                                                          \
+  do {                                                                    \
+    if (NH * t + (c) < htot) STAGE_I((c) % NH, ring_slot(rb + (c)), t + (c) / NH); \
   } while (0)
 
   // ---- fragment reads: row-in-half = wm*64 + mi*16 + frow (A) / wn*32 + ni*16 + frow (B);
@@ -87,17 +101,17 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   const int offA = (wm * 64 + frow) * 64, offB = (wn * 32 + frow) * 64;
   const int c0 = ((0 + fq) ^ fsw) << 3, c1 = ((4 + fq) ^ fsw) << 3;
   bf16x8 af[4][2], b0f[2][2], b1f[2][2];
-#define READ_A(buf, h)                                                               \
+#define READ_A(slot)                                                                 \
   do {                                                                               \
-    const bf16_t* s_ = &smem[((buf) * 4 + (h)) * HT + offA];                         \
+    const bf16_t* s_ = &smem[(slot) * HT + offA];                                    \
     _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                               \
       af[mi][0] = *(const bf16x8*)&s_[mi * 16 * 64 + c0];                            \
       af[mi][1] = *(const bf16x8*)&s_[mi * 16 * 64 + c1];                            \
     }                                                                                \
   } while (0)
-#define READ_B(dst, buf, h)                                                          \
+#define READ_B(dst, slot)                                                            \
   do {                                                                               \
-    const bf16_t* s_ = &smem[((buf) * 4 + SB + (h)) * HT + offB];                    \
+    const bf16_t* s_ = &smem[(slot) * HT + offB];                                    \
     _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                               \
       dst[ni][0] = *(const bf16x8*)&s_[ni * 16 * 64 + c0];                           \
       dst[ni][1] = *(const bf16x8*)&s_[ni * 16 * 64 + c1];                           \
@@ -130,30 +144,32 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     __builtin_amdgcn_s_setprio(0);       \
     PIN(); BARRIER(); PIN();             \
   } while (0)
-#define LANDED(more)                                                      \
-  do {                                                                    \
-    if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
-  } while (0)
-#define LANDED4(more)                                                     \
-  do {                                                                    \
-    if (more) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+// Wait until everything but the newest N DMA instructions has landed (N = 2 x half-tiles allowed in
+// flight); once the stream has run out (an expected issue was skipped) drain completely.
+#define LANDED(more, N)                                                        \
+  do {                                                                         \
+    if (more) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");            \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
   } while (0)
 
-  // ---- prologue: K-tile 0 complete + the first half-tiles (in consumption order) of K-tile 1
-  if constexpr (V == 1) {
-    STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0);
-    if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); }
-    LANDED4(nk > 1);
-  } else if constexpr (V == 2) {
-    STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, NAH - 1, 0);
-    if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
-    LANDED(nk > 1);
-  } else {
-    STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_B(0, NBH - 1, 0);
-    if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
-    LANDED(nk > 1);
+  // ---- The half-tile stream. Half-tile number h = NH*t + i (K-tile t, i-th in consumption order)
+  // lives in ring slot h % 10. A slot may be re-filled once the phase that read its previous occupant
+  // h - 10 has finished, so at the start of phase P the stream may advance to (last half-tile read
+  // before P) + 10. That keeps 5 (128x384), 6 (256x256, 128x256) half-tiles = 80-96 KiB in flight at
+  // the wait that precedes a K-tile, against 3 with a double-buffered 128 KiB layout.
+  const int htot = NH * nk;
+  int rb = 0;  // (NH * t) % RING
+  {
+    const int t = 0;
+    ISSUE(0); ISSUE(1); ISSUE(2); ISSUE(3); ISSUE(4); ISSUE(5); ISSUE(6); ISSUE(7); ISSUE(8);
+    if constexpr (V == 2) {
+      ISSUE(9);
+      LANDED(htot > 9, 12);   // K-tile 0 = half-tiles 0..3
+    } else if constexpr (V == 3) {
+      LANDED(htot > 8, 10);   // half-tiles 0..3
+    } else {
+      LANDED(htot > 8, 12);   // half-tiles 0..2
+    }
   }
   BARRIER();
   // Stagger: the second wave of every SIMD (waves 4-7 = wm 1) runs half a phase behind the first, so
@@ -167,46 +183,47 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   if (wm == 1) BARRIER();
 
   for (int t = 0; t < nk; ++t) {
-    const int b = t & 1;
-    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-    if constexpr (V == 1) {
-      if (n1) STAGE_B(b ^ 1, 1, t + 1);
-      READ_B(b0f, b, 0);
-      READ_A(b, 0);
+    if constexpr (V == 1) {         // 128x256: A B0 | B1
+      ISSUE(9);                     // slot of B1(t-1), read in the previous phase 2
+      READ_B(b0f, ring_slot(rb + 1));
+      READ_A(ring_slot(rb));
       MFMA_PART(0, 0, b0f);
-      if (n2) { STAGE_A(b, 0, t + 2); STAGE_B(b, 0, t + 2); }
-      LANDED4(n2);
-      READ_B(b1f, b, 1);
+      ISSUE(10); ISSUE(11);         // slots of A(t), B0(t)
+      LANDED(NH * t + 11 < htot, 12);
+      READ_B(b1f, ring_slot(rb + 2));
       MFMA_PART(0, 1, b1f);
-    } else if constexpr (V == 2) {
-      if (n1) STAGE_A(b ^ 1, NAH - 1, t + 1);
-      READ_B(b0f, b, 0);
-      READ_A(b, 0);
+    } else if constexpr (V == 2) {  // 256x256: A0 B0 | B1 | A1 | -
+      READ_B(b0f, ring_slot(rb + 1));
+      READ_A(ring_slot(rb));
       MFMA_PART(0, 0, b0f);
-      if (n2) STAGE_A(b, 0, t + 2);
-      READ_B(b1f, b, 1);
+      ISSUE(10); ISSUE(11);         // slots of A0(t), B0(t)
+      READ_B(b1f, ring_slot(rb + 2));
       MFMA_PART(0, 1, b1f);
-      if (n2) STAGE_B(b, 0, t + 2);
-      READ_A(b, NAH - 1);
-      MFMA_PART(NAH - 1, 1, b1f);
-      if (n2) STAGE_B(b, 1, t + 2);
-      LANDED(n2);
-      MFMA_PART(NAH - 1, 0, b0f);
-    } else {
-      if (n1) STAGE_B(b ^ 1, NBH - 1, t + 1);
-      READ_B(b0f, b, 0);
-      READ_A(b, 0);
+      ISSUE(12);                    // slot of B1(t)
+      READ_A(ring_slot(rb + 3));
+      MFMA_PART(1, 1, b1f);
+      ISSUE(13);                    // slot of A1(t)
+      LANDED(NH * t + 13 < htot, 12);
+      MFMA_PART(1, 0, b0f);
+    } else {                        // 128x384: A B0 | B1 | B2
+      ISSUE(9);                     // slot of B2(t-1)
+      READ_B(b0f, ring_slot(rb + 1));
+      READ_A(ring_slot(rb));
       MFMA_PART(0, 0, b0f);
-      if (n2) { STAGE_A(b, 0, t + 2); STAGE_B(b, 0, t + 2); }
-      READ_B(b1f, b, 1);
+      ISSUE(10); ISSUE(11);         // slots of A(t), B0(t)
+      READ_B(b1f, ring_slot(rb + 2));
       MFMA_PART(0, 1, b1f);
-      if (n2) STAGE_B(b, 1, t + 2);
-      LANDED(n2);
-      READ_B(b0f, b, NBH - 1);
-      MFMA_PART(0, NBH - 1, b0f);
+      ISSUE(12);                    // slot of B1(t)
+      LANDED(NH * t + 12 < htot, 10);
+      READ_B(b0f, ring_slot(rb + 3));
+      MFMA_PART(0, 2, b0f);
     }
+    rb += NH;
+    rb = rb >= RING ? rb - RING : rb;
   }
   if (wm == 0) BARRIER();
+#undef STAGE_I
+#undef ISSUE
 #undef STAGE_A
 #undef STAGE_B
 #undef READ_A
@@ -214,7 +231,6 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #undef MFMA_Q
 #undef MFMA_PART
 #undef LANDED
-#undef LANDED4
 
   // ---- epilogue. Loads are batched per 16-row slab — all bias vectors once, then the residual / aux
   // segments of one slab together — so a slab costs ONE memory round trip instead of one per 16x16
