@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL: see module docstring)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libplbert_hip.so")
+# PLBERT_HIP_LIB: load another build of the same C ABI (kernel timing experiments, tools/build_dbg.sh)
+LIB_PATH = os.environ.get("PLBERT_HIP_LIB") or os.path.join(HERE, "libplbert_hip.so")
 
 PLB_PARAM_NAMES = [
     "encoder.embeddings.word_embeddings.weight",
@@ -159,6 +160,8 @@ def lib():
     L.plb_launch_gemm_nt.argtypes = [C.POINTER(PlbGemmNT), C.c_int, C.c_int, vp]
     L.plb_set_gemm_nt_tile.restype = None
     L.plb_set_gemm_nt_tile.argtypes = [C.c_int]
+    L.plb_set_gemm_nt_prefetch.restype = None
+    L.plb_set_gemm_nt_prefetch.argtypes = [C.c_int]
     L.plb_launch_gemm_tn.restype = C.c_int
     L.plb_launch_gemm_tn.argtypes = [C.POINTER(PlbGemmTN), vp]
     L.plb_launch_gemm_tn_big.restype = C.c_int

@@ -41,9 +41,12 @@ def test_gemm_nt_bias_residual(M, N, K):
 @pytest.mark.parametrize("tile,M,N,K", [(256, 256, 256, 64), (256, 512, 768, 768), (256, 256, 512, 128), (256, 512, 256, 192),
                                         (384, 128, 384, 64), (384, 384, 768, 768), (384, 256, 2304, 128), (384, 128, 384, 2048),
                                         (1256, 128, 256, 64), (1256, 384, 1024, 128), (1256, 256, 512, 192), (1256, 128, 256, 1024)])
-def test_gemm_nt_big_tiles(tile, M, N, K):
-    """256x256 / 128x384 multi-phase kernels: 1, 2, 3 and many K-tiles (prologue, steady state, drain)."""
+@pytest.mark.parametrize("prefetch", [1, 0])
+def test_gemm_nt_big_tiles(tile, M, N, K, prefetch):
+    """256x256 / 128x384 / 128x256 multi-phase kernels: 1, 2, 3 and many K-tiles (prologue, steady state,
+    drain), in both K-loop forms (fragment-prefetching = default, staggered)."""
     L = _lib.lib()
+    L.plb_set_gemm_nt_prefetch(prefetch)
     A, Bw = randbf(M, K, seed=21), randbf(N, K, scale=0.05, seed=22)
     bias = torch.randn(N, device=DEV)
     res = randbf(M, N, seed=23)
@@ -55,6 +58,7 @@ def test_gemm_nt_big_tiles(tile, M, N, K):
         u, g = gemm_nt(A, Bw, N, bias=bias, act=1)
     finally:
         L.plb_set_gemm_nt_tile(0)
+        L.plb_set_gemm_nt_prefetch(-1)
     assert rel_l2(out.float(), ref) < 4e-3
     assert (out.float() - ref).abs().max() <= 1e-2 * ref.abs().max() + 1e-3
     assert rel_l2(outf, A.float() @ Bw.float().T + bias) < 1e-5

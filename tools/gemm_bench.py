@@ -16,6 +16,10 @@ SHAPES = [(16384, 768, 768), (16384, 2304, 768), (16384, 2048, 768), (16384, 768
           (8192, 8192, 8192), (4096, 4096, 4096)]
 
 
+MSTORE_ZERO = False
+WITH_RES = False
+
+
 def time_nt(L, M, N, K, act, iters=20):
     dev = "cuda"
     A = (torch.randn(M, K, device=dev)).to(torch.bfloat16)
@@ -24,9 +28,15 @@ def time_nt(L, M, N, K, act, iters=20):
     C2 = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     bias = torch.randn(N, device=dev)
     p = _lib.PlbGemmNT()
-    p.A, p.lda, p.B, p.ldb, p.M, p.N, p.K, p.Mstore = A.data_ptr(), K, B.data_ptr(), K, M, N, K, M
+    p.A, p.lda, p.B, p.ldb, p.M, p.N, p.K, p.Mstore = A.data_ptr(), K, B.data_ptr(), K, M, N, K, (0 if MSTORE_ZERO else M)
     p.bias = bias.data_ptr()
     p.C, p.ldc, p.C2, p.ldc2 = Cb.data_ptr(), N, C2.data_ptr(), N
+    if WITH_RES:
+        R = torch.randn(M, N, device=dev).to(torch.bfloat16)
+        p.res, p.ldr = R.data_ptr(), N
+    if act == 2:
+        U = torch.randn(M, N, device=dev).to(torch.bfloat16)
+        p.aux, p.ldaux = U.data_ptr(), N
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         assert L.plb_launch_gemm_nt(C.byref(p), act, 0, s) == 0
@@ -76,7 +86,14 @@ def main():
     ap.add_argument("--tn", action="store_true")
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--small", action="store_true")
+    ap.add_argument("--shapes", default="", help="M,N,K;M,N,K;... instead of the built-in NT list")
+    ap.add_argument("--prefetch", default="1", help="comma list of 0/1: NT big-tile K-loop variants to time")
+    ap.add_argument("--res", action="store_true", help="add a bf16 residual operand in the epilogue")
+    ap.add_argument("--nostore", action="store_true", help="Mstore = 0: the epilogue computes but stores nothing")
     args = ap.parse_args()
+    global MSTORE_ZERO, WITH_RES
+    MSTORE_ZERO = args.nostore
+    WITH_RES = args.res
     L = _lib.lib()
     if args.tn:
         for big in ((1,) if args.quick else (0, 1)):
@@ -84,11 +101,15 @@ def main():
                 ms, tf, sp = time_tn(L, M, N, K, big, iters=2 if args.quick else 20 if args.small else 5)
                 print(f"tn big={big} Mtot {M} N {N:5d} K {K:5d} splits {sp:3d}  {ms*1e3:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
         return
-    for tile in [int(t) for t in args.tiles.split(",")]:
-        L.plb_set_gemm_nt_tile(tile)
-        for (M, N, K) in SHAPES:
-            ms, tf = time_nt(L, M, N, K, args.act)
-            print(f"tile {tile:3d}  M {M:6d} N {N:5d} K {K:5d}  {ms*1e3:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
+    shapes = [tuple(int(v) for v in t.split(",")) for t in args.shapes.split(";")] if args.shapes else SHAPES
+    time_nt(L, *SHAPES[0], args.act)  # warm the clocks
+    for pf in [int(t) for t in args.prefetch.split(",")]:
+        L.plb_set_gemm_nt_prefetch(pf)
+        for tile in [int(t) for t in args.tiles.split(",")]:
+            L.plb_set_gemm_nt_tile(tile)
+            for (M, N, K) in shapes:
+                ms, tf = time_nt(L, M, N, K, args.act)
+                print(f"pf {pf} tile {tile:3d}  M {M:6d} N {N:5d} K {K:5d}  {ms*1e3:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
