@@ -219,6 +219,32 @@ def phoneme_loss(pred, labels, lengths, masked_indices):
     return total / count, dpred
 
 
+def token_loss(pred, token_ids, lengths):
+    """Grapheme/token-head loss. The reference defines the head (model.py:11,16) and the 4-tuple batch
+    that feeds it (dataloader.py:200-223) but no loss for it — train.py trains PhonemeOnlyModel only — so
+    this follows upstream PL-BERT's training loop (yl4579/PL-BERT train.py, ``loss_vocab``): per-sample
+    CrossEntropyLoss (mean) over the valid positions [:length], averaged over the B samples.
+    PARITY UNPINNED by the reference for the loss formula; the logits it consumes are pinned (model.py:16),
+    and tests/golden/*_dualloss.npz pins this restatement against torch autograd of exactly this formula
+    applied to the reference's MultiTaskModel.
+
+    Returns (loss, dpred): dpred = d loss / d pred, zero at padded positions.
+    """
+    B = pred.shape[0]
+    dpred = np.zeros_like(pred)
+    total = pred.dtype.type(0.0)
+    for b in range(B):
+        L = int(lengths[b])
+        rows = pred[b, :L]
+        tgt = np.asarray(token_ids[b, :L], dtype=np.int64)
+        lsm = log_softmax(rows)
+        total = total + (-lsm[np.arange(L), tgt]).mean()
+        g = np.exp(lsm)
+        g[np.arange(L), tgt] -= 1.0
+        dpred[b, :L] = g / (L * B)
+    return total / B, dpred
+
+
 def encoder_backward(cfg, P, caches, dh, dtype=np.float32):
     """Gradient of everything under ``encoder.`` given d loss / d last_hidden_state."""
     p = {k: np.asarray(v, dtype=dtype) for k, v in P.items()}
@@ -295,10 +321,12 @@ def encoder_backward(cfg, P, caches, dh, dtype=np.float32):
     return G
 
 
-def loss_and_grads(cfg, P, masked_ids, labels, lengths, masked_indices, dtype=np.float32):
+def loss_and_grads(cfg, P, masked_ids, labels, lengths, masked_indices, dtype=np.float32, token_ids=None):
     """process_batch (train.py:381-390) + backward: (loss, logits, grads-by-name).
 
     Parameters that receive no gradient in the reference (the pooler) are absent from ``grads``.
+    With ``token_ids`` (the 4-tuple batch, dataloader.py:200-223) and a token head in P the loss is
+    phoneme_loss + token_loss (dual-head training) and the second return value is (phoneme_pred, token_pred).
     """
     am = attention_mask_from_lengths(lengths)
     h, caches = encoder_forward(cfg, P, masked_ids, am, dtype)
@@ -311,6 +339,16 @@ def loss_and_grads(cfg, P, masked_ids, labels, lengths, masked_indices, dtype=np
     G["phoneme_predictor.weight"] = dpred.reshape(B * S, -1).T @ h.reshape(B * S, H)
     G["phoneme_predictor.bias"] = dpred.reshape(B * S, -1).sum(0)
     dh = dpred @ Wp
+    if token_ids is not None:
+        Wt = np.asarray(P["token_predictor.weight"], dtype)
+        bt = np.asarray(P["token_predictor.bias"], dtype)
+        tpred = h @ Wt.T + bt
+        tl, dtp = token_loss(tpred, np.asarray(token_ids), lengths)
+        G["token_predictor.weight"] = dtp.reshape(B * S, -1).T @ h.reshape(B * S, H)
+        G["token_predictor.bias"] = dtp.reshape(B * S, -1).sum(0)
+        dh = dh + dtp @ Wt
+        G.update(encoder_backward(cfg, P, caches, dh, dtype))
+        return loss + tl, (pred, tpred), G
     G.update(encoder_backward(cfg, P, caches, dh, dtype))
     return loss, pred, G
 
@@ -347,8 +385,8 @@ class AdamW:
             p -= (self.lr / bc1) * (m / denom)
 
 
-def train_step(cfg, P, opt, masked_ids, labels, lengths, masked_indices, dtype=np.float32):
+def train_step(cfg, P, opt, masked_ids, labels, lengths, masked_indices, dtype=np.float32, token_ids=None):
     """One iteration of the loop body train.py:350-357. Mutates P in place; returns the loss."""
-    loss, _, G = loss_and_grads(cfg, P, masked_ids, labels, lengths, masked_indices, dtype)
+    loss, _, G = loss_and_grads(cfg, P, masked_ids, labels, lengths, masked_indices, dtype, token_ids)
     opt.step(P, G)
     return loss

@@ -240,8 +240,71 @@ def capture_model(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, full, 
     print(tag, "written; loss", out.get("loss"), "sdpa delta", out["sdpa_max_abs_delta_valid_rows"])
 
 
+def capture_dualloss(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, n_steps, lr=1e-3):
+    """Dual-head training on the reference's MultiTaskModel: loss = calculate_phoneme_loss (train.py:107-131)
+    + the token loss of oracle.albert_np.token_loss (per-sample mean CE over [:length], mean over samples —
+    upstream PL-BERT's loss_vocab; the reference itself has no token loss). torch autograd + AdamW."""
+    pcfg = plbert_amd.AlbertConfig(**cfg_kwargs)
+    sd = plbert_amd.deterministic_state_dict(pcfg, num_phonemes, num_tokens, seed=seed)
+    labels, masked, lengths, idxs = batch
+    rs = np.random.RandomState(seed + 1000)
+    token_ids = np.zeros_like(labels)
+    for b, L in enumerate(lengths):
+        token_ids[b, :L] = rs.randint(0, num_tokens, size=L)
+    out = dict(labels=labels, masked=masked, lengths=np.array(lengths), index=obj_array(idxs), token_ids=token_ids,
+               seed=np.array(seed), num_phonemes=np.array(num_phonemes), num_tokens=np.array(num_tokens),
+               cfg_keys=np.array(list(cfg_kwargs.keys())), cfg_vals=np.array(list(cfg_kwargs.values())))
+    m = build_reference(cfg_kwargs, num_phonemes, num_tokens, sd)
+    m.train()
+    tl, tm, tt = torch.from_numpy(labels), torch.from_numpy(masked), torch.from_numpy(token_ids)
+    am = (~ref_train.length_to_mask(torch.Tensor(lengths))).int()
+    crit = torch.nn.CrossEntropyLoss()
+    opt = torch.optim.AdamW(m.parameters(), lr=lr)
+    losses, parts = [], []
+    for step in range(n_steps):
+        ph, tk = m(tm, attention_mask=am)
+        lp = ref_train.calculate_phoneme_loss(ph, tl, lengths, idxs, crit)
+        lt = 0
+        for pred_b, tgt_b, L in zip(tk, tt, lengths):
+            lt = lt + crit(pred_b[:L], tgt_b[:L])
+        lt = lt / tk.size(0)
+        loss = lp + lt
+        opt.zero_grad()
+        loss.backward()
+        if step == 0:
+            grads = {k: (p.grad.detach().numpy().copy() if p.grad is not None else None) for k, p in m.named_parameters()}
+        opt.step()
+        losses.append(float(loss.item()))
+        parts.append([float(lp.item()), float(lt.item())])
+    out["losses"] = np.array(losses, dtype=np.float64)
+    out["loss_parts"] = np.array(parts, dtype=np.float64)
+    names = [k for k, g in grads.items() if g is not None]
+    out["grad_names"] = np.array(names)
+    out["grad_none_names"] = np.array([k for k, g in grads.items() if g is None])
+    for k in names:
+        out["grad/" + k] = grads[k]
+    final = {k: v.detach().numpy() for k, v in m.state_dict().items()}
+    out["param_names"] = np.array(list(sd.keys()))
+    for k in sd:
+        out["final/" + k] = final[k]
+    np.savez_compressed(os.path.join(OUT, f"{tag}.npz"), **out, allow_pickle=True)
+    print(tag, "written; losses", losses, "parts", parts[0])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "dualloss": regenerate only the (2c) fixtures
+    tiny = dict(vocab_size=188, embedding_size=16, hidden_size=64, num_attention_heads=4,
+                intermediate_size=128, num_hidden_layers=2, max_position_embeddings=512)
+    small = dict(vocab_size=188, embedding_size=64, hidden_size=128, num_attention_heads=2,
+                 intermediate_size=256, num_hidden_layers=2, max_position_embeddings=512)
+    if only in ("", "dualloss"):
+        # (2c) dual-head training (phoneme + token loss), tiny and small
+        capture_dualloss("tiny_h64_dualloss", tiny, 188, 40, ragged_batch(2, 16, [16, 11], seed=3), seed=21, n_steps=3)
+        capture_dualloss("small_h128_dualloss", small, 188, 256, ragged_batch(3, 40, [40, 33, 7], seed=4), seed=22,
+                         n_steps=3)
+        if only:
+            return
     gen_masking()
     # (2a) tiny model of SURVEY.md §4: everything stored in full (oracle pinning)
     tiny = dict(vocab_size=188, embedding_size=16, hidden_size=64, num_attention_heads=4,

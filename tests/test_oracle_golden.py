@@ -97,3 +97,30 @@ def test_real_model_probes(name, steps):
         opt = onp.AdamW(lr=7e-5)
         losses = [float(onp.train_step(ocfg, P, opt, masked, labels, lengths, idx)) for _ in range(steps)]
         assert np.allclose(losses, g["losses"][:steps], rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["tiny_h64_dualloss", "small_h128_dualloss"])
+def test_dual_head_loss_grads_trajectory(name):
+    """Dual-head training (phoneme + token loss) on the reference's MultiTaskModel under torch autograd:
+    the token-loss formula is upstream PL-BERT's (the reference has none, see oracle.albert_np.token_loss)."""
+    g = load_golden(name)
+    ocfg, _, sd = golden_cfg(g)
+    labels, masked, lengths, idx = _batch(g)
+    tok = g["token_ids"]
+    loss, (ph, tk), G = onp.loss_and_grads(ocfg, sd, masked, labels, lengths, idx, dtype=np.float64, token_ids=tok)
+    assert abs(loss - g["losses"][0]) / g["losses"][0] < 1e-6
+    pl, _ = onp.phoneme_loss(ph, np.asarray(labels), lengths, idx)
+    tl, _ = onp.token_loss(tk, tok, lengths)
+    assert np.allclose([pl, tl], g["loss_parts"][0], rtol=1e-6)
+    for k in g["grad_names"]:
+        ref = g["grad/" + k]
+        assert np.abs(G[k] - ref).max() < 2e-6 + 1e-4 * np.abs(ref).max(), k
+    for k in g["grad_none_names"]:
+        assert k not in G
+    P = {k: v.astype(np.float64) for k, v in sd.items()}
+    opt = onp.AdamW(lr=1e-3)
+    losses = [onp.train_step(ocfg, P, opt, masked, labels, lengths, idx, dtype=np.float64, token_ids=tok)
+              for _ in g["losses"]]
+    assert np.allclose(losses, g["losses"], rtol=2e-6, atol=0)
+    for k in g["param_names"]:
+        assert np.abs(P[k] - g["final/" + k]).max() < 3e-5, k

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Timing-experiment builds of the NT pipeline GEMM: libplbert_dbgN.so = the product library with
-# gemm_big.hip compiled -DNT_DBG=N (1 no MFMA, 2 no fragment reads, 3 no DMA after the prologue,
-# 4 no K-loop barriers). Run after the normal build; use with PLBERT_HIP_LIB=... tools/gemm_bench.py.
+# gemm_big.hip compiled -DNT_DBG=N (bit mask: 1 no MFMA, 2 no fragment reads, 4 no DMA after the prologue,
+# 8 no K-loop barriers). Run after the normal build; use with PLBERT_HIP_LIB=... tools/gemm_bench.py.
 set -e
 cd "$(dirname "$0")/.."
 P=pl-bert_amd
 mkdir -p $P/build/dbg
 for n in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DNT_DBG=$n -x hip -c $P/csrc/gemm_big.hip -o $P/build/dbg/gemm_big_$n.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/build/dbg/libplbert_dbg$n.so \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o $P/build/dbg/libplbert_dbg$n.so \
     $P/build/gemm.o $P/build/dbg/gemm_big_$n.o $P/build/attn.o $P/build/rowops.o $P/build/mask.o $P/build/engine.o
   echo built $P/build/dbg/libplbert_dbg$n.so
 done

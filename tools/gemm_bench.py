@@ -87,7 +87,9 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--small", action="store_true")
     ap.add_argument("--shapes", default="", help="M,N,K;M,N,K;... instead of the built-in NT list")
-    ap.add_argument("--prefetch", default="1", help="comma list of 0/1: NT big-tile K-loop variants to time")
+    ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--libs", default="", help="other builds of libplbert_hip.so to time beside the product build")
+    ap.add_argument("--prefetch", default="-1", help="comma list of 0/1: NT big-tile K-loop variants to time")
     ap.add_argument("--res", action="store_true", help="add a bf16 residual operand in the epilogue")
     ap.add_argument("--nostore", action="store_true", help="Mstore = 0: the epilogue computes but stores nothing")
     args = ap.parse_args()
@@ -102,15 +104,31 @@ def main():
                 print(f"tn big={big} Mtot {M} N {N:5d} K {K:5d} splits {sp:3d}  {ms*1e3:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
         return
     shapes = [tuple(int(v) for v in t.split(",")) for t in args.shapes.split(";")] if args.shapes else SHAPES
+    # A/B protocol: box-to-box and minute-to-minute drift is 5-10 %, so variants are timed round-robin
+    # inside one process (other builds of the library: --libs a.so,b.so) and the median / min over --reps
+    # rounds is reported per variant.
+    libs = [("main", L)]
+    for path in [q for q in args.libs.split(",") if q]:
+        X = C.CDLL(os.path.abspath(path), mode=C.RTLD_LOCAL)
+        X.plb_set_gemm_nt_tile.argtypes = [C.c_int]
+        X.plb_set_gemm_nt_prefetch.argtypes = [C.c_int]
+        libs.append((os.path.basename(path), X))
+    variants = [(ln, lib, pf, tile) for (ln, lib) in libs for pf in [int(t) for t in args.prefetch.split(",")]
+                for tile in [int(t) for t in args.tiles.split(",")]]
     time_nt(L, *SHAPES[0], args.act)  # warm the clocks
-    for pf in [int(t) for t in args.prefetch.split(",")]:
-        L.plb_set_gemm_nt_prefetch(pf)
-        for tile in [int(t) for t in args.tiles.split(",")]:
-            L.plb_set_gemm_nt_tile(tile)
-            for (M, N, K) in shapes:
-                ms, tf = time_nt(L, M, N, K, args.act)
-                print(f"pf {pf} tile {tile:3d}  M {M:6d} N {N:5d} K {K:5d}  {ms*1e3:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
-
+    res = {}
+    for rep in range(args.reps):
+        for (M, N, K) in shapes:
+            for (ln, lib, pf, tile) in variants:
+                lib.plb_set_gemm_nt_prefetch(pf)
+                lib.plb_set_gemm_nt_tile(tile)
+                ms, tf = time_nt(lib, M, N, K, args.act)
+                res.setdefault((ln, pf, tile, M, N, K), []).append(ms)
+    for (ln, pf, tile, M, N, K), v in res.items():
+        v = sorted(v)
+        med = v[len(v) // 2]
+        print(f"{ln:14s} pf {pf:2d} tile {tile:4d}  M {M:6d} N {N:5d} K {K:5d}  median {med*1e3:8.1f} us  min {v[0]*1e3:8.1f} us"
+              f"  {2.0*M*N*K/(med*1e-3)/1e12:7.1f} TFLOP/s", flush=True)
 
 if __name__ == "__main__":
     main()
