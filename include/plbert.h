@@ -117,6 +117,18 @@ int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* lab
                      const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked, int32_t B, int32_t S,
                      float* loss, void* stream);
 
+/* Dual-head training step for MultiTaskModel (model.py:5-18: phoneme_predictor + token_predictor) fed by the
+ * 4-tuple Collater batch (dataloader.py:200-223: token_ids, labels, masked, lengths, indices). The reference
+ * defines the head and the batch but trains PhonemeOnlyModel only (train.py:266-270); the token loss here is
+ * upstream PL-BERT's: per-sample CrossEntropyLoss (mean) of token_pred[b, :len_b] against token_ids[b, :len_b],
+ * averaged over the B samples. loss = phoneme loss (as plb_loss_fwd_bwd) + token loss; loss_parts (optional)
+ * receives the two terms. token_ids int64 [B,S] in [0, num_tokens). Gradients of token_predictor.{weight,bias}
+ * are written as well and the next plb_adamw_step updates them; after a plb_loss_fwd_bwd call the token head
+ * has no gradient and is left alone, like the pooler. n_masked == 0 is allowed (phoneme term 0). */
+int plb_loss_fwd_bwd_dual(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int64_t* token_ids,
+                          const int32_t* lengths, const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked,
+                          int32_t B, int32_t S, float* loss, float* loss_parts, void* stream);
+
 /* Stands in for torch.optim.AdamW.step (train.py:272,357): decoupled weight decay on every
  * trainable parameter, bias-corrected moments; `step` counts from 1; gradients are multiplied by
  * grad_scale first (1/world_size after a sum all-reduce). Also refreshes the bf16 copies. */

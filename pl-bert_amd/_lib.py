@@ -52,7 +52,7 @@ PLB_NPARAM = len(PLB_PARAM_NAMES)
 # every symbol include/plbert.h declares (tests check the library exports all of them)
 PUBLIC_SYMBOLS = [
     "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
-    "plb_sync_weights", "plb_forward", "plb_loss_fwd_bwd", "plb_adamw_step", "plb_mask_batch",
+    "plb_sync_weights", "plb_forward", "plb_loss_fwd_bwd", "plb_loss_fwd_bwd_dual", "plb_adamw_step", "plb_mask_batch",
     "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
 ]
 
@@ -143,6 +143,8 @@ def lib():
     L.plb_forward.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.plb_loss_fwd_bwd.restype = C.c_int
     L.plb_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
+    L.plb_loss_fwd_bwd_dual.restype = C.c_int
+    L.plb_loss_fwd_bwd_dual.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     L.plb_adamw_step.restype = C.c_int
     L.plb_adamw_step.argtypes = [vp, f32, f32, f32, f32, f32, i32, f32, vp]
     L.plb_mask_batch.restype = C.c_int

@@ -41,7 +41,7 @@ std::vector<hipEvent_t> g_pool;
 const char* const kClassNames[PLB_K_NCLASS] = {
     "gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32", "gemm_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv",
     "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "reduce_slabs", "gather_scatter_rows", "cross_entropy",
-    "adamw", "cast_transpose"};
+    "adamw", "cast_transpose", "token_ce"};
 hipEvent_t prof_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
@@ -107,6 +107,11 @@ struct PlbEngine {
   int64_t o_hm, o_logm, o_dlog, o_dhm, o_rows, o_tgt, o_w, o_lrows;
   int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_logfull, o_dxe, o_ducol, o_slab2, o_scratch2;
   int64_t slab2_floats;
+  // token (grapheme) head training: padded copies and the [Tp][NTp] logit / gradient images (NT > 0 only)
+  int NTp = 0;
+  int64_t o_bt = 0, o_wtT = 0, o_tlog = 0, o_tdl = 0, o_tlrows = 0, o_tscr = 0, o_tgrad = 0, o_tloss = 0;
+  bool tok_pad_zeroed = false;  // pad columns of the transposed copy are zeroed once
+  bool tok_grads_live = false;  // the last loss call produced token-head gradients (AdamW then steps them)
   // side stream: the tail of the backward (embedding chain, bias / LayerNorm column sums) runs beside the
   // four large weight-gradient GEMMs
   hipStream_t side = nullptr;
@@ -161,7 +166,7 @@ static int tn_splits(int64_t Mtot, int N, int K, int* rows_per_split) {
   if (big) {  // one split group per XCD: 8 * s splits with s * tiles <= 32 CUs of an XCD
     int s = 32 / tiles;
     if (s < 1) s = 1;
-    splits = 8 * s;
+    splits = tiles >= 256 ? 1 : 8 * s;  // a wide output (token head) fills the chip without row splits
   }
   const int64_t maxs = Mtot / 64;
   if (splits > maxs) splits = (int)maxs;
@@ -240,8 +245,9 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   int64_t slab = 0;
   {
     const int64_t Mtot = L * Tp;
-    const int shapes[6][2] = {{(int)(3 * H), (int)H}, {(int)H, (int)H}, {(int)I, (int)H}, {(int)H, (int)I}, {(int)H, (int)E}, {e->NP, (int)H}};
-    for (int i = 0; i < 6; ++i) {
+    const int ntp = (int)rup(e->NT, 256);
+    const int shapes[7][2] = {{(int)(3 * H), (int)H}, {(int)H, (int)H}, {(int)I, (int)H}, {(int)H, (int)I}, {(int)H, (int)E}, {e->NP, (int)H}, {ntp, (int)H}};
+    for (int i = 0; i < (e->NT ? 7 : 6); ++i) {
       int rps;
       const int64_t mt = i < 4 ? Mtot : Tp;
       const int s = tn_splits(mt, shapes[i][0], shapes[i][1], &rps);
@@ -263,6 +269,18 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
     const int s2 = tn_splits(Tp, (int)H, (int)E, &rps);
     e->slab2_floats = (int64_t)s2 * H * E;
     e->o_slab2 = cv.take(e->slab2_floats * 4);
+  }
+  if (e->NT) {
+    const int64_t NTp = rup(e->NT, 256);
+    e->NTp = (int)NTp;
+    e->o_bt = cv.take(NTp * 4);
+    e->o_wtT = cv.take(rup(H, 128) * NTp * 2);
+    e->o_tlog = cv.take(Tp * NTp * 4);
+    e->o_tdl = cv.take(Tp * NTp * 2);
+    e->o_tlrows = cv.take(Tp * 4);
+    e->o_tscr = cv.take(32 * NTp * 4);
+    e->o_tgrad = cv.take(NTp * H * 4);
+    e->o_tloss = cv.take(256);
   }
   e->ws_bytes = cv.off;
   *out = e;
@@ -329,6 +347,15 @@ static int sync_transposes(PlbEngine* e, hipStream_t s) {
   TRY(plb_launch_transpose_cast(e->par(PLB_FFNO_W), H, I, e->at<bf16_t>(e->o_w2T), H, s));
   TRY(plb_launch_transpose_cast(e->par(PLB_HEAD_W), e->NP, H, e->at<bf16_t>(e->o_wpT), 256, s));
   TRY(plb_launch_transpose_cast(e->par(PLB_MAP_W), H, E, e->at<bf16_t>(e->o_winT), H, s));
+  if (e->NT && e->grads) {  // training copies of the token head: transposed weight and bias, padded to NTp columns
+    if (!e->tok_pad_zeroed) {
+      HIPTRY(hipMemsetAsync(e->at<bf16_t>(e->o_wtT), 0, (size_t)rup(H, 128) * e->NTp * 2, s));
+      HIPTRY(hipMemsetAsync(e->at<float>(e->o_bt), 0, (size_t)e->NTp * 4, s));
+      e->tok_pad_zeroed = true;
+    }
+    TRY(plb_launch_transpose_cast(e->par(PLB_TOK_W), e->NT, H, e->at<bf16_t>(e->o_wtT), e->NTp, s));
+    HIPTRY(hipMemcpyAsync(e->at<float>(e->o_bt), e->par(PLB_TOK_B), (size_t)e->NT * 4, hipMemcpyDeviceToDevice, s));
+  }
   return 0;
 }
 
@@ -454,8 +481,9 @@ static int weight_grad(PlbEngine* e, const bf16_t* A, int lda, int Ncols, const 
   memset(&t, 0, sizeof(t));
   t.A = A; t.lda = lda; t.Ncols = Ncols; t.B = Bm; t.ldb = ldb; t.Mtot = (int)Mtot; t.N = N; t.K = K;
   t.splits = tn_splits(Mtot, N, K, &t.rows_per_split);
-  if ((int64_t)t.splits * N * K > (side_slab ? e->slab2_floats : e->slab_floats)) return fail("weight_grad: slab too small");
-  t.slab = e->at<float>(side_slab ? e->o_slab2 : e->o_slab);
+  const bool direct = t.splits == 1 && N == Ncols;  // every element is written exactly once: no slab, no reduce
+  if (!direct && (int64_t)t.splits * N * K > (side_slab ? e->slab2_floats : e->slab_floats)) return fail("weight_grad: slab too small");
+  t.slab = direct ? out : e->at<float>(side_slab ? e->o_slab2 : e->o_slab);
   if (N == Ncols && tn_big(Mtot, Ncols, K)) {
     const int tok = plb_prof_begin(PLB_K_GEMM_TN, s, 2.0 * (double)Mtot * N * K, 0.0);
     TRY(plb_launch_gemm_tn_big(&t, s));
@@ -463,22 +491,25 @@ static int weight_grad(PlbEngine* e, const bf16_t* A, int lda, int Ncols, const 
   } else {
     TRY(plb_launch_gemm_tn(&t, s));
   }
-  TRY(plb_launch_reduce_slabs(t.slab, t.splits, (size_t)N * K, out, 0, s));
+  if (!direct) TRY(plb_launch_reduce_slabs(t.slab, t.splits, (size_t)N * K, out, 0, s));
   return 0;
 }
 
-extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int32_t* lengths,
-                                const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked, int32_t B,
-                                int32_t S, float* loss, void* stream) {
+// token_targets == NULL: the reference's phoneme-only step. Otherwise dual-head: loss = phoneme loss + token loss.
+static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int64_t* token_targets,
+                             const int32_t* lengths, const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked,
+                             int32_t B, int32_t S, float* loss, float* loss_parts, void* stream) {
   if (check_shape(e, B, S, "plb_loss_fwd_bwd")) return 1;
   if (!e->grads) return fail("plb_loss_fwd_bwd: no gradient buffer bound");
   if (!masked_ids || !labels || !idx_offsets || !loss) return fail("plb_loss_fwd_bwd: null argument");
   if (n_masked < 0 || n_masked > e->NMcap) return fail("plb_loss_fwd_bwd: n_masked %d out of range", n_masked);
+  if (token_targets && !e->NT) return fail("plb_loss_fwd_bwd_dual: the engine has no token head (num_tokens = 0)");
   hipStream_t s = (hipStream_t)stream;
   const int E = e->E, H = e->H, I = e->I, L = e->L, NP = e->NP;
   const int T = B * S;
   const int64_t Tp = rup(T, 128);
-  if (n_masked == 0) {  // train.py:129 — zero loss, nothing to back-propagate
+  e->tok_grads_live = token_targets != nullptr;
+  if (n_masked == 0 && !token_targets) {  // train.py:129 — zero loss, nothing to back-propagate
     HIPTRY(hipMemsetAsync(loss, 0, sizeof(float), s));
     HIPTRY(hipMemsetAsync(e->grads, 0, (size_t)e->ptrain * 4, s));
     return 0;
@@ -496,26 +527,61 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   float* logm = e->at<float>(e->o_logm);
   bf16_t* dlog = e->at<bf16_t>(e->o_dlog);
   bf16_t* dhm = e->at<bf16_t>(e->o_dhm);
-  TRY(plb_launch_ce_prepare(idx_offsets, idx_flat, labels, B, S, rows, tgt, w, s));
-  TRY(plb_launch_gather_rows(xL, H, rows, n_masked, NM, H, hm, H, s));
-  PlbGemmNT g;
-  memset(&g, 0, sizeof(g));
-  g.A = hm; g.lda = H; g.B = e->wbf(PLB_HEAD_W); g.ldb = H; g.M = NM; g.N = NP; g.K = H; g.Mstore = NM;
-  g.bias = e->par(PLB_HEAD_B); g.Cf = logm; g.ldcf = 256;
-  TRY(plb_launch_gemm_nt(&g, 0, 1, s));
-  TRY(plb_launch_ce_fwd_bwd(logm, 256, NP, tgt, w, n_masked, NM, lrows, dlog, 256, s));
-  TRY(plb_launch_sum_rows(lrows, n_masked, loss, s));
-  if (weight_grad(e, dlog, 256, 256, hm, H, NM, NP, H, e->grd(PLB_HEAD_W), s)) return 1;
   float* scratch = e->at<float>(e->o_scratch);
-  TRY(plb_launch_colsum(dlog, 1, (size_t)NM, 256, 256, e->grd(PLB_HEAD_B), NP, 0, scratch, 8, s));
-  memset(&g, 0, sizeof(g));
-  g.A = dlog; g.lda = 256; g.B = e->at<bf16_t>(e->o_wpT); g.ldb = 256; g.M = NM; g.N = H; g.K = 256; g.Mstore = NM;
-  g.C = dhm; g.ldc = H;
-  TRY(plb_launch_gemm_nt(&g, 0, 0, s));
   bf16_t* dy = e->at<bf16_t>(e->o_dy0);
   bf16_t* dy_other = e->at<bf16_t>(e->o_dy1);
+  PlbGemmNT g;
   HIPTRY(hipMemsetAsync(dy, 0, (size_t)Tp * H * 2, s));
-  TRY(plb_launch_scatter_rows(dhm, H, rows, n_masked, H, dy, H, s));
+  if (n_masked > 0) {
+    TRY(plb_launch_ce_prepare(idx_offsets, idx_flat, labels, B, S, rows, tgt, w, s));
+    TRY(plb_launch_gather_rows(xL, H, rows, n_masked, NM, H, hm, H, s));
+    memset(&g, 0, sizeof(g));
+    g.A = hm; g.lda = H; g.B = e->wbf(PLB_HEAD_W); g.ldb = H; g.M = NM; g.N = NP; g.K = H; g.Mstore = NM;
+    g.bias = e->par(PLB_HEAD_B); g.Cf = logm; g.ldcf = 256;
+    TRY(plb_launch_gemm_nt(&g, 0, 1, s));
+    TRY(plb_launch_ce_fwd_bwd(logm, 256, NP, tgt, w, n_masked, NM, lrows, dlog, 256, s));
+    TRY(plb_launch_sum_rows(lrows, n_masked, loss, s));
+    if (weight_grad(e, dlog, 256, 256, hm, H, NM, NP, H, e->grd(PLB_HEAD_W), s)) return 1;
+    TRY(plb_launch_colsum(dlog, 1, (size_t)NM, 256, 256, e->grd(PLB_HEAD_B), NP, 0, scratch, 8, s));
+    memset(&g, 0, sizeof(g));
+    g.A = dlog; g.lda = 256; g.B = e->at<bf16_t>(e->o_wpT); g.ldb = 256; g.M = NM; g.N = H; g.K = 256; g.Mstore = NM;
+    g.C = dhm; g.ldc = H;
+    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    TRY(plb_launch_scatter_rows(dhm, H, rows, n_masked, H, dy, H, s));
+  } else {  // dual-head step on a batch without masked phonemes: phoneme loss 0, its head gets zero gradients
+    HIPTRY(hipMemsetAsync(loss, 0, sizeof(float), s));
+    HIPTRY(hipMemsetAsync(e->grd(PLB_HEAD_W), 0, (size_t)(e->psize[PLB_HEAD_W] + e->psize[PLB_HEAD_B]) * 4, s));
+  }
+  if (loss_parts) HIPTRY(hipMemcpyAsync(loss_parts, loss, sizeof(float), hipMemcpyDeviceToDevice, s));
+
+  // ---- token (grapheme) head over every valid position: logits, CE rows, head gradients, dH -----------------
+  // The whole [Tp][NTp] logit image is materialised (4.2 GB fp32 + 2.1 GB bf16 gradient at 16384 x 64000: a
+  // small part of 288 GB), so the three GEMMs run on the pipeline kernels with K or N = NTp in one launch each.
+  if (token_targets) {
+    const int NT = e->NT, NTp = e->NTp;
+    float* tlog = e->at<float>(e->o_tlog);
+    bf16_t* tdl = e->at<bf16_t>(e->o_tdl);
+    float* tlrows = e->at<float>(e->o_tlrows);
+    float* tloss = e->at<float>(e->o_tloss);
+    memset(&g, 0, sizeof(g));
+    g.A = xL; g.lda = H; g.B = e->wbf(PLB_TOK_W); g.ldb = H; g.M = (int)Tp; g.N = NTp; g.K = H; g.Mstore = (int)Tp;
+    g.bias = e->at<float>(e->o_bt); g.Cf = tlog; g.ldcf = NTp;
+    TRY(plb_launch_gemm_nt(&g, 0, 1, s));
+    TRY(plb_launch_token_ce(tlog, NTp, NT, token_targets, lengths, B, S, (int)Tp, tlrows, tdl, NTp, s));
+    TRY(plb_launch_sum_rows(tlrows, T, tloss, s));
+    TRY(plb_launch_add_scalar(loss, loss, tloss, s));
+    if (loss_parts) HIPTRY(hipMemcpyAsync(loss_parts + 1, tloss, sizeof(float), hipMemcpyDeviceToDevice, s));
+    float* gw = NTp == NT ? e->grd(PLB_TOK_W) : e->at<float>(e->o_tgrad);
+    if (weight_grad(e, tdl, NTp, NTp, xL, H, Tp, NTp, H, gw, s)) return 1;
+    if (NTp != NT) HIPTRY(hipMemcpyAsync(e->grd(PLB_TOK_W), gw, (size_t)NT * H * 4, hipMemcpyDeviceToDevice, s));
+    TRY(plb_launch_colsum(tdl, 1, (size_t)Tp, NTp, NTp, e->grd(PLB_TOK_B), NT, 0, e->at<float>(e->o_tscr), 32, s));
+    // dH += dlogits · Wt, on top of the scattered phoneme-head rows (in place: a tile reads its residual
+    // before its own stores)
+    memset(&g, 0, sizeof(g));
+    g.A = tdl; g.lda = NTp; g.B = e->at<bf16_t>(e->o_wtT); g.ldb = NTp; g.M = (int)Tp; g.N = H; g.K = NTp; g.Mstore = (int)Tp;
+    g.res = dy; g.ldr = H; g.C = dy; g.ldc = H;
+    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+  }
 
   // ---- layers in reverse --------------------------------------------------------------------------------
   const int du_rows = plb_gemm_nt_colpart_rows((int)Tp, I, H);  // ffn.bias gradient from the dU GEMM's epilogue
@@ -634,6 +700,22 @@ extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const i
   return 0;
 }
 
+extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int32_t* lengths,
+                                const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked, int32_t B,
+                                int32_t S, float* loss, void* stream) {
+  return loss_fwd_bwd_impl(e, masked_ids, labels, nullptr, lengths, idx_offsets, idx_flat, n_masked, B, S, loss, nullptr,
+                           stream);
+}
+
+extern "C" int plb_loss_fwd_bwd_dual(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels,
+                                     const int64_t* token_ids, const int32_t* lengths, const int32_t* idx_offsets,
+                                     const int32_t* idx_flat, int32_t n_masked, int32_t B, int32_t S, float* loss,
+                                     float* loss_parts, void* stream) {
+  if (!token_ids) return fail("plb_loss_fwd_bwd_dual: token_ids is null");
+  return loss_fwd_bwd_impl(e, masked_ids, labels, token_ids, lengths, idx_offsets, idx_flat, n_masked, B, S, loss,
+                           loss_parts, stream);
+}
+
 extern "C" int plb_mask_batch(const int64_t* labels, const int32_t* lengths, int32_t B, int32_t S, uint64_t seed,
                               uint32_t step, float word_pred_prob, float phoneme_mask_prob, float replace_prob,
                               int32_t mask_id, int32_t sep_id, int64_t* masked, int32_t* idx_offsets, int32_t* idx_flat,
@@ -657,5 +739,10 @@ extern "C" int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, 
   hipStream_t s = (hipStream_t)stream;
   TRY(plb_launch_adamw(e->params, e->grads, e->m, e->v, e->at<bf16_t>(e->o_wbf), (size_t)e->ptrain, lr, beta1, beta2, eps,
                        weight_decay, step, grad_scale, s));
+  if (e->tok_grads_live) {  // token head: trained only by dual-head steps (no gradient, no update — as the pooler)
+    const int64_t o = e->poff[PLB_TOK_W];
+    TRY(plb_launch_adamw(e->params + o, e->grads + o, e->m + o, e->v + o, e->at<bf16_t>(e->o_wbf) + o,
+                         (size_t)(e->ptotal - o), lr, beta1, beta2, eps, weight_decay, step, grad_scale, s));
+  }
   return sync_transposes(e, s);
 }

@@ -12,7 +12,7 @@ extern "C" {
 enum PlbKernelClass {
   PLB_K_GEMM_NT = 0, PLB_K_GEMM_NT_GELU, PLB_K_GEMM_NT_GELUBWD, PLB_K_GEMM_NT_F32, PLB_K_GEMM_TN,
   PLB_K_ATTN_FWD, PLB_K_ATTN_BWD_DQ, PLB_K_ATTN_BWD_DKV, PLB_K_LN_FWD, PLB_K_LN_BWD, PLB_K_EMBED_FWD,
-  PLB_K_EMBED_BWD, PLB_K_COLSUM, PLB_K_REDUCE, PLB_K_ROWS, PLB_K_CE, PLB_K_ADAMW, PLB_K_CAST, PLB_K_NCLASS
+  PLB_K_EMBED_BWD, PLB_K_COLSUM, PLB_K_REDUCE, PLB_K_ROWS, PLB_K_CE, PLB_K_ADAMW, PLB_K_CAST, PLB_K_TOKEN_CE, PLB_K_NCLASS
 };
 int plb_prof_begin(int cls, hipStream_t s, double flops, double bytes);
 void plb_prof_end(int tok, hipStream_t s);
@@ -117,6 +117,11 @@ int plb_launch_ce_fwd_bwd(const float* logits, int ldl, int V, const int32_t* tg
                           float* loss_rows, bf16_t* dlogits, int ldd, hipStream_t stream);
 // loss[0] = sum(loss_rows[0..n))  (single block, deterministic order)
 int plb_launch_sum_rows(const float* x, int n, float* out, hipStream_t stream);
+// token-head loss rows over a wide vocabulary (oracle.albert_np.token_loss); rows >= B*S, padded positions and
+// columns >= NT of dlogits are zero-filled
+int plb_launch_token_ce(const float* logits, int ldl, int NT, const int64_t* targets, const int32_t* lengths, int B, int S,
+                        int rows, float* loss_rows, bf16_t* dlogits, int ldd, hipStream_t stream);
+int plb_launch_add_scalar(float* out, const float* a, const float* b, hipStream_t stream);
 
 // Device-side word masking (mask.hip): labels [B,S] -> masked [B,S], counts [B], idx_padded [B,S],
 // then offsets [B+1] and flat (CSR of the modified positions).

@@ -56,6 +56,7 @@ class HipEngine:
             self.ws_bytes = int(self.L.plb_workspace_bytes(h))
             self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
             self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+            self._loss_parts = torch.zeros(2, dtype=torch.float32, device=self.device)
         _lib.check(self.L.plb_bind(h, self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
                                    self.exp_avg_sq.data_ptr(), self.workspace.data_ptr(), self.ws_bytes), "plb_bind")
         self._synced_version = -1
@@ -137,9 +138,12 @@ class HipEngine:
                    "plb_forward")
         return hid, ph, tk
 
-    def loss_fwd_bwd(self, masked_ids, labels, lengths, idx_offsets, idx_flat, n_masked):
+    def loss_fwd_bwd(self, masked_ids, labels, lengths, idx_offsets, idx_flat, n_masked, token_ids=None):
         """Loss of one batch + gradients of every trainable parameter into ``self.grads``.
-        Returns the 1-element device tensor holding the loss (no host sync)."""
+        Returns the 1-element device tensor holding the loss (no host sync).
+        With ``token_ids`` (int64 [B,S], the 4-tuple Collater's first element) the step is dual-head:
+        loss = phoneme loss + token loss, ``self.loss_parts`` holds the two terms and the token head's
+        gradients are produced too."""
         self._ensure_synced()
         masked_ids = self._dev_i64(masked_ids)
         labels = self._dev_i64(labels)
@@ -147,11 +151,35 @@ class HipEngine:
         lens = self._dev_i32(lengths)
         offs = self._dev_i32(idx_offsets)
         flat = self._dev_i32(idx_flat)
+        if token_ids is not None:
+            if not self.num_tokens:
+                raise ValueError("token_ids given but the engine was built without a token head (num_tokens = 0)")
+            tok = self._dev_i64(token_ids)
+            if tok.shape != masked_ids.shape:
+                raise ValueError("token_ids must have the shape of the phoneme batch")
+            _lib.check(self.L.plb_loss_fwd_bwd_dual(self.handle, masked_ids.data_ptr(), labels.data_ptr(), tok.data_ptr(),
+                                                    None if lens is None else lens.data_ptr(), offs.data_ptr(),
+                                                    flat.data_ptr() if n_masked else None, int(n_masked), B, S,
+                                                    self._loss.data_ptr(), self._loss_parts.data_ptr(), self._stream()),
+                       "plb_loss_fwd_bwd_dual")
+            return self._loss
         _lib.check(self.L.plb_loss_fwd_bwd(self.handle, masked_ids.data_ptr(), labels.data_ptr(),
                                            None if lens is None else lens.data_ptr(), offs.data_ptr(),
                                            flat.data_ptr() if n_masked else None, int(n_masked), B, S,
                                            self._loss.data_ptr(), self._stream()), "plb_loss_fwd_bwd")
         return self._loss
+
+    @property
+    def loss_parts(self):
+        """(phoneme loss, token loss) of the last dual-head call, on the device."""
+        return self._loss_parts
+
+    @property
+    def token_range(self):
+        """[start, end) of token_predictor.{weight,bias} in the flat buffers (empty without a token head)."""
+        if not self.num_tokens:
+            return (self.total, self.total)
+        return (self.layout["token_predictor.weight"][0], self.total)
 
     def adamw_step(self, step, lr=7e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale=1.0):
         _lib.check(self.L.plb_adamw_step(self.handle, lr, betas[0], betas[1], eps, weight_decay, int(step),

@@ -31,6 +31,17 @@ class StagedBatch:
     flat: torch.Tensor            # int32 [n_masked]
     n_masked: int
     n_tokens: int
+    token_ids: torch.Tensor | None = None  # int64 [B,S]: grapheme-token targets of the 4-tuple Collater (dual-head)
+
+
+def validate_token_ids(token_ids, shape, lengths, num_tokens):
+    """Targets of the token head must be class ids at every valid position (the kernel indexes with them)."""
+    tok = np.asarray(token_ids)
+    if tok.shape != tuple(shape):
+        raise ValueError("token_ids must have the shape of the phoneme batch")
+    valid = np.arange(shape[1])[None, :] < np.asarray(lengths)[:, None]
+    if tok[valid].min(initial=0) < 0 or tok[valid].max(initial=0) >= num_tokens:
+        raise ValueError("token id outside [0, num_tokens)")
 
 
 def validate_batch(labels, masked, lengths, masked_indices, vocab_size):
@@ -57,24 +68,29 @@ def validate_batch(labels, masked, lengths, masked_indices, vocab_size):
 
 
 class PLBertTrainer:
-    """PhonemeOnlyModel + AdamW(lr) of train.py:266-272 on one GPU, optionally data parallel."""
+    """PhonemeOnlyModel + AdamW(lr) of train.py:266-272 on one GPU, optionally data parallel.
+    ``num_tokens > 0`` builds MultiTaskModel's second head (model.py:11); batches staged with ``token_ids``
+    then train both heads (loss = phoneme loss + token loss, see include/plbert.h plb_loss_fwd_bwd_dual)."""
 
     def __init__(self, cfg, num_phonemes, max_batch=32, max_seq=512, lr=7e-5, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.01, device=None, seed=0, state_dict=None, process_group=None, force_collectives=False):
-        self.engine = HipEngine(cfg, num_phonemes, 0, max_batch=max_batch, max_seq=max_seq, device=device)
+                 weight_decay=0.01, device=None, seed=0, state_dict=None, process_group=None, force_collectives=False,
+                 num_tokens=0):
+        self.engine = HipEngine(cfg, num_phonemes, num_tokens, max_batch=max_batch, max_seq=max_seq, device=device)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
         self.reducer = GradReducer(process_group, device=self.engine.device, force=force_collectives)
         self.world = self.reducer.world
-        sd = state_dict if state_dict is not None else reference_init_state_dict(cfg, num_phonemes, 0, seed=seed)
+        sd = state_dict if state_dict is not None else reference_init_state_dict(cfg, num_phonemes, num_tokens, seed=seed)
         self.engine.load_state_dict(sd)
         if self.reducer.active:  # DDP's start-up broadcast of rank 0's parameters (SURVEY.md §2 row 7 (i))
             self.reducer.broadcast_(self.engine.params)
             self.engine.sync_weights()
 
-    def stage_batch(self, labels, masked, lengths, masked_indices, validate=True):
+    def stage_batch(self, labels, masked, lengths, masked_indices, validate=True, token_ids=None):
         if validate:
             validate_batch(labels, masked, lengths, masked_indices, self.engine.cfg.vocab_size)
+            if token_ids is not None:
+                validate_token_ids(token_ids, np.asarray(masked).shape, lengths, self.engine.num_tokens)
         dev = self.engine.device
         masked_t = torch.as_tensor(np.asarray(masked), dtype=torch.int64).to(dev)
         labels_t = torch.as_tensor(np.asarray(labels), dtype=torch.int64).to(dev)
@@ -82,24 +98,29 @@ class PLBertTrainer:
         lens = np.asarray(lengths, dtype=np.int32)
         lengths_t = None if (lens == S).all() else torch.from_numpy(lens).to(dev)
         off, flat = masked_indices_to_csr(masked_indices)
+        tok_t = None if token_ids is None else torch.as_tensor(np.asarray(token_ids), dtype=torch.int64).to(dev)
         return StagedBatch(masked_t, labels_t, lengths_t, torch.from_numpy(off).to(dev), torch.from_numpy(flat).to(dev),
-                           int(off[-1]), int(lens.sum()))
+                           int(off[-1]), int(lens.sum()), tok_t)
 
     def loss_and_grads(self, batch: StagedBatch):
         return self.engine.loss_fwd_bwd(batch.masked, batch.labels, batch.lengths, batch.offsets, batch.flat,
-                                        batch.n_masked)
+                                        batch.n_masked, token_ids=batch.token_ids)
 
-    def all_reduce_grads(self):
+    def all_reduce_grads(self, dual=False):
         """Sum the trainable gradient range over ranks on a side stream (RCCL over xGMI); the AdamW
-        kernel applies the 1/world factor."""
+        kernel applies the 1/world factor. A dual-head step also carries the token head's gradients."""
         self.reducer.all_reduce_(self.engine.grads[: self.engine.trainable])
+        if dual:
+            a, b = self.engine.token_range
+            self.reducer.all_reduce_(self.engine.grads[a:b])
 
     def step(self, batch: StagedBatch):
         """zero_grad + backward + optimizer.step of train.py:355-357; returns the local loss (device)."""
         loss = self.loss_and_grads(batch)
-        if batch.n_masked == 0 and self.world == 1:
+        dual = batch.token_ids is not None
+        if batch.n_masked == 0 and self.world == 1 and not dual:
             return loss  # reference: zero-loss fallback has no graph, the optimizer sees no gradients
-        self.all_reduce_grads()
+        self.all_reduce_grads(dual)
         self.step_count += 1
         self.engine.adamw_step(self.step_count, self.lr, self.betas, self.eps, self.weight_decay,
                                grad_scale=1.0 / self.world)
@@ -115,29 +136,39 @@ class _FusedLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, engine, names, batch, *params):
-        loss = engine.loss_fwd_bwd(batch.masked, batch.labels, batch.lengths, batch.offsets, batch.flat, batch.n_masked)
-        ctx.engine, ctx.names = engine, names
+        loss = engine.loss_fwd_bwd(batch.masked, batch.labels, batch.lengths, batch.offsets, batch.flat, batch.n_masked,
+                                   token_ids=batch.token_ids)
+        ctx.engine, ctx.names, ctx.dual = engine, names, batch.token_ids is not None
         return loss[0].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
         eng = ctx.engine
+        ta, tb = eng.token_range
         grads = []
         for n in ctx.names:
             off, size, shp = eng.layout[n]
-            g = eng.grads[off:off + size].view(shp) if off + size <= eng.trainable else None
-            grads.append(g)
+            has = off + size <= eng.trainable or (ctx.dual and off >= ta)  # pooler: never; token head: dual steps
+            grads.append(eng.grads[off:off + size].view(shp) if has else None)
         # d(loss)/d(param) is already in the flat buffer; scale by the upstream gradient on the device
         # (1.0 for loss.backward(); no host sync to find out)
         eng.grads[: eng.trainable].mul_(grad_out)
+        if ctx.dual:
+            eng.grads[ta:tb].mul_(grad_out)
         return (None, None, None, *grads)
 
 
 def stage_reference_batch(engine, batch, validate=True):
-    """(labels, masked, lengths, masked_indices) as PhonemeOnlyCollater returns it -> StagedBatch."""
+    """(labels, masked, lengths, masked_indices) as PhonemeOnlyCollater returns it, or the 5-tuple
+    (token_ids, labels, masked, lengths, masked_indices) of Collater (dataloader.py:200-223) -> StagedBatch."""
+    token_ids = None
+    if len(batch) == 5:
+        token_ids, *batch = batch
     labels, masked, lengths, idx = batch
     if validate:
         validate_batch(labels, masked, lengths, idx, engine.cfg.vocab_size)
+        if token_ids is not None:
+            validate_token_ids(token_ids, np.asarray(masked).shape, lengths, engine.num_tokens)
     dev = engine.device
     masked_t = torch.as_tensor(np.asarray(masked), dtype=torch.int64).to(dev)
     labels_t = torch.as_tensor(np.asarray(labels), dtype=torch.int64).to(dev)
@@ -145,8 +176,9 @@ def stage_reference_batch(engine, batch, validate=True):
     lens = np.asarray(lengths, dtype=np.int32)
     lengths_t = None if (lens == S).all() else torch.from_numpy(lens).to(dev)
     off, flat = masked_indices_to_csr(idx)
+    tok_t = None if token_ids is None else torch.as_tensor(np.asarray(token_ids), dtype=torch.int64).to(dev)
     return StagedBatch(masked_t, labels_t, lengths_t, torch.from_numpy(off).to(dev), torch.from_numpy(flat).to(dev),
-                       int(off[-1]), int(lens.sum()))
+                       int(off[-1]), int(lens.sum()), tok_t)
 
 
 def device_mask_batch(labels, lengths=None, seed=1, step=0, word_pred_prob=0.15, phoneme_mask_prob=0.8, replace_prob=0.1,
@@ -187,10 +219,12 @@ def process_batch(model, batch, criterion=None, accelerator=None):
     """train.py:381-390 — ``batch = (phoneme_labels, masked_phonemes, input_lengths, masked_indices)``.
     ``criterion`` / ``accelerator`` are accepted for signature compatibility: the loss is the
     reference's calculate_phoneme_loss with nn.CrossEntropyLoss() (train.py:107-131, 215), computed by
-    the HIP engine. Returns a 0-dim tensor; under autograd its ``backward()`` fills ``param.grad``."""
+    the HIP engine. Returns a 0-dim tensor; under autograd its ``backward()`` fills ``param.grad``.
+    A 5-tuple batch (Collater, dataloader.py:200-223: token_ids first) on a MultiTaskModel trains both heads:
+    phoneme loss + token loss (plb_loss_fwd_bwd_dual)."""
     engine = model.engine
     staged = batch if isinstance(batch, StagedBatch) else stage_reference_batch(engine, batch)
-    if staged.n_masked == 0:  # train.py:129
+    if staged.n_masked == 0 and staged.token_ids is None:  # train.py:129
         return torch.tensor(0.0, device=engine.device, requires_grad=True)
     names, params = [], []
     for n, p in model.named_parameters():
@@ -199,7 +233,7 @@ def process_batch(model, batch, criterion=None, accelerator=None):
     if torch.is_grad_enabled():
         return _FusedLoss.apply(engine, names, staged, *params)
     return engine.loss_fwd_bwd(staged.masked, staged.labels, staged.lengths, staged.offsets, staged.flat,
-                               staged.n_masked)[0].clone()
+                               staged.n_masked, token_ids=staged.token_ids)[0].clone()
 
 
 class AdamW:
@@ -216,6 +250,7 @@ class AdamW:
         self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.step_count = 0
         self.grad_scale = 1.0
+        self._token_stepped = False  # the token head has optimizer state once a dual-head step updated it
         by_id = {id(p): n for n, p in model.named_parameters()}
         self._names = [by_id[id(p)] for p in self.param_list]
 
@@ -233,8 +268,11 @@ class AdamW:
             # autograd may have handed the Parameter a copy of its gradient slice (or user code replaced
             # / clipped .grad): whatever .grad holds now is what the fused update must consume
             off, size, shp = e.layout[n]
-            if p.grad is not None and off + size <= e.trainable and p.grad.data_ptr() != e.grads.data_ptr() + 4 * off:
+            in_range = off + size <= e.trainable or off >= e.token_range[0]
+            if p.grad is not None and in_range and p.grad.data_ptr() != e.grads.data_ptr() + 4 * off:
                 e.grads[off:off + size].view(shp).copy_(p.grad)
+            if p.grad is not None and off >= e.token_range[0]:
+                self._token_stepped = True
         self.step_count += 1
         d = self.defaults
         self.engine.adamw_step(self.step_count, d["lr"], d["betas"], d["eps"], d["weight_decay"], self.grad_scale)
@@ -250,7 +288,7 @@ class AdamW:
         if self.step_count > 0:
             for i, n in enumerate(self._names):
                 off, size, shp = e.layout[n]
-                if off + size <= e.trainable:
+                if off + size <= e.trainable or (self._token_stepped and off >= e.token_range[0]):
                     state[i] = {"step": torch.tensor(float(self.step_count)),
                                 "exp_avg": e.exp_avg[off:off + size].view(shp).clone(),
                                 "exp_avg_sq": e.exp_avg_sq[off:off + size].view(shp).clone()}
