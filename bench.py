@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--model", choices=["base", "large"], default="base",
                     help="base = BASELINE configs[1] (hidden 768 / 12 layers, the bench line); large = configs[3] "
                          "(hidden 1024 / 24 layers / 16 heads / FFN 4096, batch 16): utilisation report only")
+    ap.add_argument("--num-tokens", type=int, default=0,
+                    help="> 0: dual-head step (MultiTaskModel: phoneme loss + grapheme/token loss over a vocabulary "
+                         "of this size, e.g. 64000) instead of the reference's phoneme-only step; a second, "
+                         "separately reported workload")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the RCCL process group and run the gradient all-reduce even at world size 1 "
                          "(rehearses the N>1 code path on a one-GPU box)")
@@ -115,9 +119,15 @@ def main():
         model_desc = "hidden 768 / 12 shared layers / FFN 2048 / 12 heads"
     B, S = args.batch, args.seq
     trainer = PLBertTrainer(cfg, num_phonemes=len(plbert_amd.symbols), max_batch=B, max_seq=S, lr=7e-5,
-                            device=f"cuda:{local_rank}", seed=0, force_collectives=args.force_dist)
+                            device=f"cuda:{local_rank}", seed=0, force_collectives=args.force_dist,
+                            num_tokens=args.num_tokens)
     labels, masked, lengths, idx = plbert_amd.synthetic_batch(B, S, seed=1234 + rank)
-    batch = trainer.stage_batch(labels, masked, lengths, idx)  # resident in HBM before timing
+    token_ids = None
+    if args.num_tokens:
+        token_ids = np.random.RandomState(4321 + rank).randint(0, args.num_tokens, size=(B, S)).astype(np.int64)
+        flop_per_token += 3 * 2 * cfg.hidden_size * args.num_tokens  # token head fwd + dgrad + wgrad
+        model_desc += f" + token head {args.num_tokens}"
+    batch = trainer.stage_batch(labels, masked, lengths, idx, token_ids=token_ids)  # resident in HBM before timing
 
     def sync_all():
         if dist.is_initialized():
@@ -162,7 +172,7 @@ def main():
                                                 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.num_tokens:
         cpu = cpu_baseline(args.cpu_seconds)
 
     if rank == 0:
@@ -171,7 +181,8 @@ def main():
             "metric": "phoneme-tokens/sec", "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"PL-BERT masked-phoneme training step (fwd+loss+bwd+allreduce+AdamW), ALBERT "
+            "config": {"workload": f"PL-BERT {'dual-head (phoneme + token loss)' if args.num_tokens else 'masked-phoneme'} "
+                                   f"training step (fwd+loss+bwd+allreduce+AdamW), ALBERT "
                                    f"{model_desc}, seq_len {S}, batch {B} per GPU",
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
             "step_loss": round(loss_val, 5),

@@ -137,3 +137,32 @@ def test_standalone_encoder_loads_stripped_checkpoint():
     v = (am != 0).numpy()
     assert np.abs(out.last_hidden_state.cpu().numpy()[v] - g["hidden"][v]).max() < 6e-2
     assert tuple(out.pooler_output.shape) == (3, pcfg.hidden_size)
+
+
+def test_dual_head_loop_body_on_multitask_model():
+    """The reference loop body on MultiTaskModel with the 5-tuple Collater batch (dataloader.py:200-223):
+    both heads receive gradients, the pooler none; losses follow the reference-captured trajectory."""
+    g = load_golden("small_h128_dualloss")
+    m, pcfg, sd = _make(g, multitask=True)
+    opt = plbert_amd.AdamW(m.parameters(), lr=1e-3, model=m)
+    batch = (torch.from_numpy(g["token_ids"]), torch.from_numpy(g["labels"]), torch.from_numpy(g["masked"]),
+             [int(x) for x in g["lengths"]], [list(map(int, x)) for x in g["index"]])
+    m.train()
+    losses = []
+    for _ in g["losses"]:
+        loss = plbert_amd.process_batch(m, batch, criterion=torch.nn.CrossEntropyLoss(), accelerator=None)
+        opt.zero_grad()
+        loss.backward()
+        assert m.token_predictor.weight.grad is not None and m.phoneme_predictor.weight.grad is not None
+        assert m.encoder.pooler.weight.grad is None
+        opt.step()
+        losses.append(float(loss.item()))
+    assert np.allclose(losses, g["losses"], rtol=2e-3)
+    st = opt.state_dict()
+    names = [n for n, _ in m.named_parameters()]
+    assert names.index("token_predictor.weight") in st["state"]       # the token head now has optimizer state
+    assert names.index("encoder.pooler.weight") not in st["state"]
+    with pytest.raises(ValueError):
+        bad = torch.from_numpy(g["token_ids"]).clone()
+        bad[0, 0] = int(g["num_tokens"])                               # out-of-range class id
+        plbert_amd.process_batch(m, (bad,) + batch[1:], None, None)
