@@ -86,6 +86,11 @@ def cpu_baseline(budget_s):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout. Native libraries write there too (RCCL prints a version banner
+    # when the first communicator is created), so fd 1 points at stderr until the line is printed.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -189,7 +194,10 @@ def main():
             "step_mfma_frac_wall": round(flop_per_token * B * S / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
