@@ -107,8 +107,9 @@ class PLBertTrainer:
                                         batch.n_masked, token_ids=batch.token_ids)
 
     def all_reduce_grads(self, dual=False):
-        """Sum the trainable gradient range over ranks on a side stream (RCCL over xGMI); the AdamW
-        kernel applies the 1/world factor. A dual-head step also carries the token head's gradients."""
+        """Sum the trainable gradient range over ranks (RCCL over xGMI, one collective in the step's stream:
+        see dist.GradReducer); the AdamW kernel applies the 1/world factor. A dual-head step also carries
+        the token head's gradients."""
         self.reducer.all_reduce_(self.engine.grads[: self.engine.trainable])
         if dual:
             a, b = self.engine.token_range
