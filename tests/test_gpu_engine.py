@@ -206,3 +206,41 @@ def test_zero_masked_indices_gives_zero_loss_and_grads():
     loss = eng.loss_fwd_bwd(masked, labels, lens, off0, flat[:0], 0)
     assert float(loss.item()) == 0.0
     assert float(eng.grads[: eng.trainable].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,S,lengths", [(1, 1, [1]), (1, 512, [512]), (5, 33, [33, 32, 2, 1, 1]), (3, 65, [65, 64, 63])])
+def test_edge_shapes_against_oracle(B, S, lengths):
+    """Edges of the batch space: a single token, the maximum sequence length, samples of length 1 and 2 (a
+    softmax over one key), lengths straddling the 64-key attention tile."""
+    ocfg = onp.Config(embedding_size=64, hidden_size=128, num_attention_heads=2, intermediate_size=256,
+                      num_hidden_layers=2)
+    pcfg = plbert_amd.AlbertConfig(vocab_size=188, embedding_size=64, hidden_size=128, num_attention_heads=2,
+                                   intermediate_size=256, num_hidden_layers=2, max_position_embeddings=512)
+    sd = plbert_amd.deterministic_state_dict(pcfg, 188, seed=13)
+    rs = np.random.RandomState(100 * B + S)
+    labels = np.zeros((B, S), np.int64)
+    masked = np.zeros((B, S), np.int64)
+    idx = []
+    for b, L in enumerate(lengths):
+        labels[b, :L] = rs.randint(1, 185, size=L)
+        masked[b, :L] = labels[b, :L]
+        ii = sorted(rs.choice(L, size=max(1, L // 5), replace=False).tolist())
+        masked[b, ii] = 185
+        idx.append(ii)
+    loss_ref, pred_ref, G = onp.loss_and_grads(ocfg, sd, masked, labels, lengths, idx)
+    eng = HipEngine(pcfg, 188, 0, max_batch=B, max_seq=S)
+    eng.load_state_dict(sd)
+    _, ph, _ = eng.forward(masked, np.asarray(lengths, np.int32))
+    v = np.arange(S)[None, :] < np.asarray(lengths)[:, None]
+    assert np.abs(ph.cpu().numpy()[v] - pred_ref[v]).max() < 3e-2
+    off, flat = plbert_amd.masked_indices_to_csr(idx)
+    loss = eng.loss_fwd_bwd(masked, labels, np.asarray(lengths, np.int32), off, flat, int(off[-1]))
+    assert abs(float(loss.item()) - float(loss_ref)) / float(loss_ref) < 1e-3
+    # with one key per query the softmax is constant and the q/k gradients are exactly 0 in the oracle: compare
+    # absolute errors against the largest gradient of the step where a tensor's own norm is (near) zero
+    scale = max(float(np.sqrt((np.asarray(w, np.float64) ** 2).sum())) for w in G.values())
+    for k, want in G.items():
+        got = eng.view(k, of=eng.grads).cpu().double()
+        want = torch.as_tensor(want).double()
+        err = float((got - want).norm())
+        assert err <= 5e-2 * float(want.norm()) + 1e-4 * scale, (k, err, float(want.norm()), scale)
