@@ -720,14 +720,15 @@ extern "C" int plb_launch_gemm_tn_big(const PlbGemmTN* p, hipStream_t stream) {
 
 // K-loop form: 1 interleaved (reads / DMA issues in the MFMA shadows), 0 staggered two-barrier loop,
 // -1 (default) per tile: measured on 16384 x {768, 2048, 2304} x {768, 2048, 2304}, interleaved wins by
-// 5-8 % on 128x384 and 128x256, staggered by 5-10 % on 256x256 (whose phase 3 has nothing to interleave
-// and phase 4 twelve reads).
+// 5-8 % on 128x384 and 128x256, staggered by 5-10 % on a plain 256x256 launch (whose phase 3 has nothing to
+// interleave and phase 4 twelve reads) — but with the GELU epilogues (the only 256x256 launches of the model:
+// 16384 x 2048 x 768) interleaved wins again by 6 %: 68.7 vs 72.8 us forward, 70.0 vs 74.7 us backward.
 static int g_nt_prefetch = -1;
 extern "C" void plb_set_gemm_nt_prefetch(int on) { g_nt_prefetch = on; }
 
 // tile = 256: 256x256 (M % 256, N % 256); 384: 128x384 (M % 128, N % 384); 1256: 128x256 (M % 128, N % 256).
 extern "C" int plb_launch_gemm_nt_big(const PlbGemmNT* p, int tile, int act, int out_f32, hipStream_t stream) {
-  const bool pf = g_nt_prefetch < 0 ? (tile != 256) : (g_nt_prefetch != 0);
+  const bool pf = g_nt_prefetch < 0 ? (tile != 256 || act != 0) : (g_nt_prefetch != 0);
   if (pf)
     return tile == 384 ? launch_big<3, true>(p, act, out_f32, stream)
            : tile == 1256 ? launch_big<1, true>(p, act, out_f32, stream) : launch_big<2, true>(p, act, out_f32, stream);
