@@ -1,31 +1,32 @@
 // Large-tile NT GEMMs with a multi-phase, counted-vmcnt LDS-DMA pipeline (gfx950).
 //
-// Why: at a 128x128 tile the operand stream into LDS is 64 FLOP/B — ~9 TB/s of L2->LDS traffic at
-// 600 TFLOP/s, and the kernel is bound by that load path, not by the MFMA pipe. Here one workgroup of
-// 8 waves (2 per SIMD) owns a CU, the tile is 256x256 (128 FLOP/B) or 128x384 (96 FLOP/B), and three
-// 16 KiB half-tiles of LDS-DMA stay in flight across barriers (s_waitcnt vmcnt(6), never 0 in steady
-// state). Tile choice is by wave quantisation on 256 CUs: N = 768 -> 128x384 gives exactly 256 tiles
-// at M = 16384 (256x256 would give 192: a quarter of the chip idle), N = 2304 -> 768 tiles = 3 per CU.
+// Why: at a 128x128 tile the operand stream into LDS is 64 FLOP/B, and a CU's LDS-DMA path (one 1 KiB
+// global_load_lds per 16 clocks through the texture addresser: ~94 GB/s per CU measured) bounds the kernel
+// long before the MFMA pipe. Here one workgroup of 8 waves (2 per SIMD) owns a CU, the tile is 256x256
+// (128 FLOP/B), 128x384 (96 FLOP/B) or 128x256 (85 FLOP/B), and 4-6 16-KiB half-tiles of LDS-DMA stay in
+// flight across barriers (counted s_waitcnt vmcnt(N), never 0 in steady state). Tile choice is by wave
+// quantisation on 256 CUs: N = 768 -> 128x384 gives exactly 256 tiles at M = 16384 (256x256 would give 192:
+// a quarter of the chip idle), N = 2304 -> 768 tiles = 3 per CU, N = 2048 -> 512 tiles of 256x256.
 //
-// A K-tile (64 deep) is four 128-row half-tiles in LDS, slots per buffer:
-//   256x256: A0 A1 B0 B1        128x384: A B0 B1 B2              (2 buffers x 4 x 16 KiB = 128 KiB)
+// A K-tile (64 deep) is 3-4 128-row half-tiles, streamed through a 10-slot ring (the whole 160 KiB LDS) in
+// consumption order:   256x256: A0 B0 B1 A1      128x384: A B0 B1 B2      128x256: A B0 B1
 // 8 waves = 2 (M) x 4 (N). Wave (wm, wn) owns rows {mh*128 + wm*64 + 0..63} and columns
 // {nh*128 + wn*32 + 0..31} of every (mh, nh): its output is interleaved over the half-tiles, so one
-// phase (16 MFMAs 16x16x32 = a 64x32 patch) reads fragments of ONE A half and ONE B half, and the
-// half-tiles of a K-tile are consumed (and their slots freed for the DMA of K-tile t+2) in order:
-//   256x256:  ph1 A0,B0 -> (0,0) | ph2 B1 -> (0,1) | ph3 A1 -> (1,1) | ph4 (1,0), no reads
-//             DMA issue: ph1 A1(t+1) | ph2 A0(t+2) | ph3 B0(t+2) | ph4 B1(t+2), then vmcnt(6)
-//   128x384:  ph1 A,B0 -> nh 0     | ph2 B1 -> nh 1 | ph3 B2 -> nh 2
-//             DMA issue: ph1 B2(t+1) | ph2 A(t+2),B0(t+2) | ph3 B1(t+2), then vmcnt(6)
-// The vmcnt(6) in the last phase leaves exactly the three newest half-tiles (all of K-tile t+2) in
-// flight, so K-tile t+1 has landed. Two raw s_barriers per phase (asm: __syncthreads() would drain
-// vmcnt to 0) and a half-phase stagger between the two waves of each SIMD — see the loop comment.
+// phase (16 MFMAs 16x16x32 = a 64x32 patch) reads fragments of ONE A half and ONE B half:
+//   256x256:  ph1 A0,B0 -> (0,0) | ph2 B1 -> (0,1) | ph3 A1 -> (1,1) | ph4 (1,0)
+//   128x384:  ph1 A,B0 -> nh 0   | ph2 B1 -> nh 1  | ph3 B2 -> nh 2
+// A slot is re-filled once the phase that read its previous occupant is behind a barrier. Barriers are raw
+// s_barrier (asm: __syncthreads() would drain vmcnt to 0). Two forms of the K loop exist, chosen per launch
+// by measurement (plb_launch_gemm_nt_big): "interleaved" (fragment reads of the next phase and the DMA
+// issues dealt into the MFMA shadows, one barrier per phase) and "staggered" (two barriers per phase, the
+// two waves of a SIMD half a phase apart) — see the comments at the loops.
 #include "common.h"
 #include "plbert_kernels.h"
 #include "gemm_epilogue.h"
 
-// Timing experiments only (tools/build_dbg.sh): -DNT_DBG=1 no MFMA, 2 no fragment reads, 3 no DMA after the
-// prologue, 4 no barriers in the K loop. Results are garbage in those builds; the shipped library has 0.
+// Timing experiments only (tools/build_dbg.sh): -DNT_DBG=<bit mask> 1 no MFMA, 2 no fragment reads, 4 no DMA
+// after the prologue, 8 no barriers in the K loop (results are garbage with any of those), 16 print the shader
+// clock over the K loop (results stay valid). The shipped library has 0.
 #ifndef NT_DBG
 #define NT_DBG 0
 #endif
@@ -48,7 +49,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 #define BARRIER()                                        \
   do {                                                   \
     __builtin_amdgcn_s_waitcnt(0xC07F);                  \
-    if (NT_DBG != 4) asm volatile("s_barrier" ::: "memory"); \
+    if (!(NT_DBG & 8)) asm volatile("s_barrier" ::: "memory"); \
   } while (0)
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bm = logical / nbn, bn = logical % nbn;
   const int nk = p.K >> 6;
+#if NT_DBG & 16
+  const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- staging: each wave DMAs rows [(2w+j)*8, +8) of a half-tile, j = 0,1 (1 KiB per instruction);
   // the XOR swizzle of the image is applied to the per-lane SOURCE chunk
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 // issue half-tile number NH*t + c of the stream (c is a literal), if it exists
 #define ISSUE(c)                                                          \
   do {                                                                    \
-    if ((NT_DBG != 3 || PRO) && NH * t + (c) < htot) STAGE_I((c) % NH, ring_slot(rb + (c)), t + (c) / NH); \
+    if ((!(NT_DBG & 4) || PRO) && NH * t + (c) < htot) STAGE_I((c) % NH, ring_slot(rb + (c)), t + (c) / NH); \
   } while (0)
 
   // ---- fragment reads: row-in-half = wm*64 + mi*16 + frow (A) / wn*32 + ni*16 + frow (B);
@@ -116,14 +120,14 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   // two A and two B fragment buffers (indices are literals everywhere: plain registers). The prefetching
   // loop ping-pongs them; the staggered loop uses afr[0] and both B buffers.
   bf16x8 afr[2][4][2], bfr[2][2][2];
-  if (NT_DBG == 2) {
+  if (NT_DBG & 2) {
     __builtin_memset(afr, 0, sizeof(afr));
     __builtin_memset(bfr, 0, sizeof(bfr));
   }
 #define READ_A(ab, slot)                                                             \
   do {                                                                               \
     const bf16_t* s_ = &smem[(slot) * HT + offA];                                    \
-    if (NT_DBG != 2) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                               \
+    if (!(NT_DBG & 2)) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                               \
       afr[ab][mi][0] = *(const bf16x8*)&s_[mi * 16 * 64 + c0];                       \
       afr[ab][mi][1] = *(const bf16x8*)&s_[mi * 16 * 64 + c1];                       \
     }                                                                                \
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #define READ_B(bb, slot)                                                             \
   do {                                                                               \
     const bf16_t* s_ = &smem[(slot) * HT + offB];                                    \
-    if (NT_DBG != 2) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                               \
+    if (!(NT_DBG & 2)) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                               \
       bfr[bb][ni][0] = *(const bf16x8*)&s_[ni * 16 * 64 + c0];                       \
       bfr[bb][ni][1] = *(const bf16x8*)&s_[ni * 16 * 64 + c1];                       \
     }                                                                                \
@@ -149,7 +153,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   // swapped MFMA operands: D[row = n][col = m] -> each lane owns 4 consecutive n of one row m
 #define MFMA_Q(mh, nh, ab, bb)                                                                                 \
   do {                                                                                                         \
-    if (NT_DBG != 1) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
+    if (!(NT_DBG & 1)) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                         \
         _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
           acc[mh][mi][nh][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[bb][ni][kk], afr[ab][mi][kk],     \
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 // one MFMA of the 16 of a phase: j -> (kk, mi, ni)
 #define MF(mh, nh, ab, bb, j)                                                                          \
   do {                                                                                                 \
-    if (NT_DBG != 1)                                                                                   \
+    if (!(NT_DBG & 1))                                                                                   \
       acc[mh][((j) >> 1) & 3][nh][(j) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
           bfr[bb][(j) & 1][(j) >> 3], afr[ab][((j) >> 1) & 3][(j) >> 3], acc[mh][((j) >> 1) & 3][nh][(j) & 1], 0, 0, 0); \
     PIN();                                                                                             \
@@ -233,13 +237,13 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 // one ds_read_b128 of an A half (i = 0..7) / a B half (i = 0..3)
 #define RA(ab, slot, i)                                                                                \
   do {                                                                                                 \
-    if (NT_DBG != 2)                                                                                   \
+    if (!(NT_DBG & 2))                                                                                   \
       afr[ab][(i) >> 1][(i) & 1] = *(const bf16x8*)&smem[(slot) * HT + offA + ((i) >> 1) * 16 * 64 + (((i) & 1) ? c1 : c0)]; \
     PIN();                                                                                             \
   } while (0)
 #define RB(bb, slot, i)                                                                                \
   do {                                                                                                 \
-    if (NT_DBG != 2)                                                                                   \
+    if (!(NT_DBG & 2))                                                                                   \
       bfr[bb][(i) >> 1][(i) & 1] = *(const bf16x8*)&smem[(slot) * HT + offB + ((i) >> 1) * 16 * 64 + (((i) & 1) ? c1 : c0)]; \
     PIN();                                                                                             \
   } while (0)
@@ -375,6 +379,13 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #undef PHASE
 #undef LANDED
 
+#if NT_DBG & 16
+  if (blockIdx.x == 17 && tid == 0) {
+    const unsigned long long dc = __builtin_readcyclecounter() - dbg_c0, dr = __builtin_amdgcn_s_memrealtime() - dbg_r0;
+    printf("K loop: %llu cycles in %llu ticks of 100 MHz -> %.0f MHz, %.3f us per K-tile\n", dc, dr,
+           (double)dc / ((double)dr / 100.0), (double)dr / 100.0 / nk);
+  }
+#endif
   // ---- epilogue. Loads are batched per 16-row slab — all bias vectors once, then the residual / aux
   // segments of one slab together — so a slab costs ONE memory round trip instead of one per 16x16
   // tile. bf16 outputs leave through LDS: in MFMA layout one store instruction is 16 rows x 32 B, i.e. 16
