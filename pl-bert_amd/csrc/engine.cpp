@@ -105,7 +105,7 @@ struct PlbEngine {
   int64_t o_dqkv, o_dpre1, o_du, o_dpre2;
   int64_t o_dy0, o_dy1, o_da, o_dctx, o_de;
   int64_t o_hm, o_logm, o_dlog, o_dhm, o_rows, o_tgt, o_w, o_lrows;
-  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_logfull, o_dxe, o_ducol, o_slab2, o_scratch2;
+  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_dxe, o_ducol, o_slab2, o_scratch2;
   int64_t slab2_floats;
   // token (grapheme) head training: padded copies and the [Tp][NTp] logit / gradient images (NT > 0 only)
   int NTp = 0;
@@ -588,7 +588,6 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
   bf16_t* da = e->at<bf16_t>(e->o_da);
   bf16_t* dctx = e->at<bf16_t>(e->o_dctx);
   for (int l = L - 1; l >= 0; --l) {
-    bf16_t* x_unused = nullptr; (void)x_unused;
     bf16_t* qkv = e->at<bf16_t>(e->o_qkv) + (int64_t)l * Tp * 3 * H;
     bf16_t* ctx = e->at<bf16_t>(e->o_ctx) + (int64_t)l * Tp * H;
     bf16_t* pre1 = e->at<bf16_t>(e->o_pre1) + (int64_t)l * Tp * H;

@@ -33,6 +33,10 @@ typedef struct {
 } PlbGemmNT;
 int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream);
 int plb_gemm_nt_colpart_rows(int M, int N, int K);  // rows of colpart written for this shape (0: unsupported)
+// Tuning / test hooks (not part of include/plbert.h): force a tile (0 = per-shape policy; 128, 256, 384, 1256 =
+// 128x256) or a K-loop form (-1 = per-launch policy, 1 interleaved, 0 staggered) for the launches that follow.
+void plb_set_gemm_nt_tile(int tile);
+void plb_set_gemm_nt_prefetch(int on);
 
 // slab[split][N][K] = A[rows,N]^T · B[rows,K] over the split's rows; Mtot%64==0, rows_per_split%64==0,
 // Ncols (readable columns of A) %8==0, K%8==0.
