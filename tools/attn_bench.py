@@ -28,6 +28,8 @@ def bench(L, B, S, NH, iters=30):
     p.dctx, p.lddctx, p.delta, p.dqkv, p.lddqkv = dctx.data_ptr(), H, delta.data_ptr(), dqkv.data_ptr(), 3 * H
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     out = []
+    L.plb_profile_enable.argtypes = [C.c_int]
+    L.plb_profile_read.argtypes = [C.c_void_p] * 4
     for fn in (L.plb_launch_attn_fwd, L.plb_launch_attn_bwd):
         for _ in range(3):
             assert fn(C.byref(p), s) == 0
@@ -38,6 +40,21 @@ def bench(L, B, S, NH, iters=30):
         e1.record()
         torch.cuda.synchronize()
         out.append(e0.elapsed_time(e1) / iters * 1e3)
+    # split of the backward into its two kernels: the library's own per-launch HIP events
+    n = L.plb_profile_num_classes()
+    ms, cnt = (C.c_double * n)(), (C.c_int64 * n)()
+    fl, by = (C.c_double * n)(), (C.c_double * n)()
+    L.plb_profile_enable(1)
+    for _ in range(10):
+        L.plb_launch_attn_bwd(C.byref(p), s)
+    torch.cuda.synchronize()
+    L.plb_profile_read(ms, cnt, fl, by)
+    L.plb_profile_enable(0)
+    L.plb_profile_class_name.restype = C.c_char_p
+    names = [L.plb_profile_class_name(i).decode() for i in range(n)]
+    split = {names[i]: ms[i] / cnt[i] * 1e3 for i in range(n) if cnt[i]}
+    out.append(split.get("attn_bwd_dq", 0.0))
+    out.append(split.get("attn_bwd_dkv", 0.0))
     return out
 
 
@@ -53,13 +70,15 @@ def main():
     for rep in range(args.reps):
         for (B, S, NH) in ((32, 512, 12),):
             for name, L in libs:
-                f, b = bench(L, B, S, NH)
-                res.setdefault((name, B, S, NH), []).append((f, b))
+                f, b, dq, dkv = bench(L, B, S, NH)
+                res.setdefault((name, B, S, NH), []).append((f, b, dq, dkv))
     for (name, B, S, NH), v in res.items():
         f = sorted(x[0] for x in v)[len(v) // 2]
         b = sorted(x[1] for x in v)[len(v) // 2]
+        dq = sorted(x[2] for x in v)[len(v) // 2]
+        dkv = sorted(x[3] for x in v)[len(v) // 2]
         unit = B * NH * S * S * 64.0
-        print(f"{name:18s} B {B} S {S} heads {NH}  fwd {f:7.2f} us ({4*unit/f/1e6:6.1f} TFLOP/s)   bwd(dq+dkv) {b:7.2f} us ({8*unit/b/1e6:6.1f} TFLOP/s credited)", flush=True)
+        print(f"{name:14s} fwd {f:6.2f} us ({4*unit/f/1e6:5.0f} TF)  bwd {b:7.2f} us ({8*unit/b/1e6:5.0f} TF credited) = dq {dq:6.2f} + dkv {dkv:6.2f}", flush=True)
 
 
 if __name__ == "__main__":
