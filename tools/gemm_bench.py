@@ -98,10 +98,20 @@ def main():
     WITH_RES = args.res
     L = _lib.lib()
     if args.tn:
-        for big in ((1,) if args.quick else (0, 1)):
-            for (M, N, K) in (TN_SHAPES[:2] if args.quick else TN_SHAPES[4:] if args.small else TN_SHAPES):
-                ms, tf, sp = time_tn(L, M, N, K, big, iters=2 if args.quick else 20 if args.small else 5)
-                print(f"tn big={big} Mtot {M} N {N:5d} K {K:5d} splits {sp:3d}  {ms*1e3:9.1f} us  {tf:7.1f} TFLOP/s", flush=True)
+        libs = [("main", L)] + [(os.path.basename(q), C.CDLL(os.path.abspath(q), mode=C.RTLD_LOCAL))
+                                for q in args.libs.split(",") if q]
+        res = {}
+        shapes_tn = TN_SHAPES[:2] if args.quick else TN_SHAPES[4:] if args.small else TN_SHAPES
+        for rep in range(args.reps):
+            for (M, N, K) in shapes_tn:
+                for (ln, lib) in libs:
+                    ms, tf, sp = time_tn(lib, M, N, K, 1, iters=3)
+                    res.setdefault((ln, M, N, K, sp), []).append(ms)
+        for (ln, M, N, K, sp), v in res.items():
+            v = sorted(v)
+            med = v[len(v) // 2]
+            print(f"{ln:14s} tn big Mtot {M} N {N:5d} K {K:5d} splits {sp:3d}  median {med*1e3:9.1f} us  "
+                  f"{2.0*M*N*K/(med*1e-3)/1e12:7.1f} TFLOP/s", flush=True)
         return
     shapes = [tuple(int(v) for v in t.split(",")) for t in args.shapes.split(";")] if args.shapes else SHAPES
     # A/B protocol: box-to-box and minute-to-minute drift is 5-10 %, so variants are timed round-robin
