@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU budget of the cpu_baseline sample")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that fill roofline.traffic (N = 1 only)")
     ap.add_argument("--model", choices=["base", "large"], default="base",
                     help="base = BASELINE configs[1] (hidden 768 / 12 layers, the bench line); large = configs[3] "
                          "(hidden 1024 / 24 layers / 16 heads / FFN 4096, batch 16): utilisation report only")
@@ -82,6 +84,62 @@ def cpu_baseline(budget_s):
     return {"value": round(n * B * S / dt, 1), "unit": "tokens/s", "cores": threads, "kind": "port",
             "sample": f"{n} full training steps (fwd+loss+bwd+AdamW, fp32 numpy oracle) of {B}x{S} tokens, "
                       f"768/12 model, {dt:.1f} s wall"}
+
+
+# profiler class -> does a rocprof kernel name belong to it (template arguments: <tile, ACT, OUTF32, loop form>)
+def _in_class(cls, name):
+    import re
+    if cls in ("gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32"):
+        m = re.search(r"gemm_nt_big_kernel<\d+, (\d+), (false|true), (?:false|true)>", name) or \
+            re.search(r"gemm_nt_kernel<(\d+), (false|true)>", name)
+        if not m:
+            return False
+        act, f32 = int(m.group(1)), m.group(2) == "true"
+        return {"gemm_nt": act == 0 and not f32, "gemm_nt_gelu": act == 1, "gemm_nt_gelubwd": act == 2,
+                "gemm_nt_f32": f32}[cls]
+    return cls.replace("_fwd", "").replace("_bwd", "") in name or cls in name
+
+
+def pmc_traffic(cls):
+    """HBM bytes per launch of the dominant kernel class from PMC counters, as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 --pmc passes (kernel trace only beside them) over a short
+    child run of this same script; FETCH_SIZE is in KiB and counts a wide streaming read at half its bytes on
+    gfx950 (x 1024 x 2), WRITE_SIZE in KiB (x 1024). Returns None when the profiler is unavailable."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if not shutil.which("rocprofv3"):
+        return None
+    tot, launches = {}, 0
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="plb_pmc_")
+        try:
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--",
+                   sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                   "--no-roofline", "--no-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            s, n = 0.0, 0
+            for row in csv.DictReader(open(files[0])):
+                if row["Counter_Name"] == ctr and _in_class(cls, row["Kernel_Name"]):
+                    s += float(row["Counter_Value"])
+                    n += 1
+            if n == 0:
+                return None
+            tot[ctr] = s / n
+            launches = n
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = tot["FETCH_SIZE"] * 1024 * 2, tot["WRITE_SIZE"] * 1024
+    return {"bytes": round(fetch + write), "fetch": round(fetch), "write": round(write), "launches_sampled": launches}
 
 
 def main():
@@ -189,6 +247,13 @@ def main():
                                                sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
                         "step_mfma_frac": round(flop_per_token * B * S / (total_ms / args.steps * 1e-3) / 1e12
                                                 / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+    if roofline is not None and world == 1 and not dist.is_initialized() and not args.no_traffic:
+        t = pmc_traffic(roofline["kernel"])
+        if t is not None:
+            roofline["traffic"] = t["bytes"]
+            roofline["traffic_detail"] = {"unit": "B per launch, PMC", "fetch(FETCH_SIZE*1024*2)": t["fetch"],
+                                          "write(WRITE_SIZE*1024)": t["write"], "launches_sampled": t["launches_sampled"]}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.num_tokens:
