@@ -121,7 +121,7 @@ def pmc_traffic(cls):
                    sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
                    "--no-roofline", "--no-traffic"]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None
@@ -245,6 +245,7 @@ def main():
                         "share_of_kernel_time": round(dom["ms"] / total_ms, 3),
                         "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in
                                                sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+                        "_algo_bytes": round(dom["bytes"] / dom["launches"]),
                         "step_mfma_frac": round(flop_per_token * B * S / (total_ms / args.steps * 1e-3) / 1e12
                                                 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
@@ -253,7 +254,10 @@ def main():
         if t is not None:
             roofline["traffic"] = t["bytes"]
             roofline["traffic_detail"] = {"unit": "B per launch, PMC", "fetch(FETCH_SIZE*1024*2)": t["fetch"],
-                                          "write(WRITE_SIZE*1024)": t["write"], "launches_sampled": t["launches_sampled"]}
+                                          "write(WRITE_SIZE*1024)": t["write"], "launches_sampled": t["launches_sampled"],
+                                          "algorithmic": roofline.pop("_algo_bytes", None)}
+    if roofline is not None:
+        roofline.pop("_algo_bytes", None)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.num_tokens:

@@ -253,17 +253,18 @@ extern "C" int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipS
   const int cls = out_f32 ? PLB_K_GEMM_NT_F32 : act == 1 ? PLB_K_GEMM_NT_GELU : act == 2 ? PLB_K_GEMM_NT_GELUBWD : PLB_K_GEMM_NT;
   const int tile = pick_tile(p);
   if (p->colpart && tile == 128) return 1;  // column-sum partials exist in the big-tile kernels only
+  // algorithmic HBM bytes of the launch: each operand and each output once
+  const double mnk = (double)p->M * p->N * p->K;
+  const double algo_bytes = 2.0 * ((double)p->M * p->K + (double)p->N * p->K) +
+                            (double)p->M * p->N * (out_f32 ? 4 : act == 1 ? 4 : 2) +
+                            (p->res ? 2.0 * p->M * p->N : 0.0) + (act == 2 ? 2.0 * p->M * p->N : 0.0);
   if (tile != 128) {
-    const int tokb = plb_prof_begin(cls, stream, 2.0 * (double)p->M * p->N * p->K, 0.0);
+    const int tokb = plb_prof_begin(cls, stream, 2.0 * mnk, algo_bytes);
     const int rc = plb_launch_gemm_nt_big(p, tile, act, out_f32, stream);
     plb_prof_end(tokb, stream);
     return rc;
   }
-  const double mnk = (double)p->M * p->N * p->K;
-  const int tok = plb_prof_begin(cls, stream, 2.0 * mnk,
-                                 2.0 * ((double)p->M * p->K + (double)p->N * p->K) +
-                                     (double)p->M * p->N * (out_f32 ? 4 : act == 1 ? 4 : 2) +
-                                     (p->res ? 2.0 * p->M * p->N : 0.0) + (act == 2 ? 2.0 * p->M * p->N : 0.0));
+  const int tok = plb_prof_begin(cls, stream, 2.0 * mnk, algo_bytes);
   if (out_f32) {
     if (act != 0) return 1;
     hipLaunchKernelGGL((gemm_nt_kernel<0, true>), grid, block, 0, stream, *p);
