@@ -116,3 +116,38 @@ def test_validate_batch_rejects_bad_inputs():
         validate_batch(lab * 200, lab, [8, 5], [[0], [0]], 188)   # id outside the vocabulary
     with pytest.raises(ValueError):
         validate_batch(lab, lab, [9, 5], [[0], [0]], 188)         # length beyond S
+
+
+def test_validate_token_ids_and_five_tuple_staging_checks():
+    from plbert_amd.train import validate_token_ids
+
+    tok = np.array([[3, 9, 0, 0], [1, 2, 5, 7]])
+    validate_token_ids(tok, (2, 4), [2, 4], 10)                       # padding positions are not checked
+    with pytest.raises(ValueError):
+        validate_token_ids(tok, (2, 4), [2, 4], 9)                    # class id 9 needs num_tokens >= 10
+    with pytest.raises(ValueError):
+        validate_token_ids(tok[:, :3], (2, 4), [2, 4], 10)            # shape must match the phoneme batch
+    bad = tok.copy()
+    bad[1, 0] = -1
+    with pytest.raises(ValueError):
+        validate_token_ids(bad, (2, 4), [2, 4], 10)
+
+
+def test_bench_maps_profiler_classes_to_rocprof_kernel_names():
+    """bench.py attributes PMC traffic to the dominant profiler class by kernel name (template arguments
+    <tile, ACT, OUTF32, loop form> of the pipeline GEMM, <ACT, OUTF32> of the 128x128 one)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    big = "void (anonymous namespace)::gemm_nt_big_kernel<%d, %d, %s, true>(PlbGemmNT)"
+    assert bench._in_class("gemm_nt", big % (3, 0, "false"))
+    assert not bench._in_class("gemm_nt", big % (2, 1, "false"))
+    assert bench._in_class("gemm_nt_gelu", big % (2, 1, "false"))
+    assert bench._in_class("gemm_nt_gelubwd", big % (2, 2, "false"))
+    assert bench._in_class("gemm_nt_f32", big % (2, 0, "true")) and not bench._in_class("gemm_nt", big % (2, 0, "true"))
+    assert bench._in_class("gemm_nt", "void (anonymous namespace)::gemm_nt_kernel<0, false>(PlbGemmNT)")
+    assert bench._in_class("gemm_tn", "(anonymous namespace)::gemm_tn_big_kernel(PlbGemmTN)")
+    assert not bench._in_class("gemm_nt", "(anonymous namespace)::gemm_tn_big_kernel(PlbGemmTN)")
+    assert bench._in_class("attn_bwd_dkv", "(anonymous namespace)::attn_bwd_dkv_kernel(PlbAttn)")
