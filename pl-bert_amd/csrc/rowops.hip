@@ -149,6 +149,8 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(PlbEmbed p, int P) {
 
 // ------------------------------------------------------------------------- LayerNorm(H) (A7/A8)
 // nn.LayerNorm over the last dim, biased variance, eps inside the sqrt. NCH = ceil(H/256).
+// Rows are dealt to workgroups through xcd_remap: XCD x then owns the same contiguous eighth of the token rows
+// as in the GEMMs and the attention kernels that produce / consume them (worth 0.05 ms per step, measured).
 // A wave handles LN_R rows per iteration with all their loads issued before the first reduction:
 // the kernels are pure HBM streams and one row per wave (3 x 8 B per lane) left them latency-bound.
 constexpr int LN_R = 2;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(PlbLayerNorm p) {
     g[i] = (c < H) ? *(const float4*)(p.gamma + c) : make_float4(0, 0, 0, 0);
     b[i] = (c < H) ? *(const float4*)(p.beta + c) : make_float4(0, 0, 0, 0);
   }
-  for (int t0 = (blockIdx.x * 4 + wave) * LN_R; t0 < p.T; t0 += gridDim.x * 4 * LN_R) {
+  for (int t0 = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * LN_R; t0 < p.T; t0 += gridDim.x * 4 * LN_R) {
     uint2 u[LN_R][NCH];
 #pragma unroll
     for (int r = 0; r < LN_R; ++r) {
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
   }
-  for (int t0 = (blockIdx.x * 4 + wave) * LN_R; t0 < p.T; t0 += gridDim.x * 4 * LN_R) {
+  for (int t0 = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * LN_R; t0 < p.T; t0 += gridDim.x * 4 * LN_R) {
     uint2 ux[LN_R][NCH], ud[LN_R][NCH];
     float mean[LN_R], rstd[LN_R];
 #pragma unroll
