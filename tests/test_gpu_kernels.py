@@ -200,3 +200,40 @@ def test_colsum():
     assert L.plb_launch_colsum(x.data_ptr(), 1, R, N, 784, out.data_ptr(), N - 4, 0, scratch.data_ptr(), 16, stream()) == 0
     torch.cuda.synchronize()
     assert rel_l2(out, x[:, : N - 4].float().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("NT,ldd,B,S,lens", [(1000, 1024, 2, 24, [24, 7]), (40, 256, 3, 5, None), (4096, 4096, 1, 130, [77])])
+def test_token_ce_rows(NT, ldd, B, S, lens):
+    """Wide-vocabulary CE rows against torch: loss rows with weight 1 / (B * len), gradient (softmax - onehot) * w in
+    bf16, zeros on padded positions, on rows >= B*S and on columns >= NT."""
+    L = _lib.lib()
+    L.plb_launch_token_ce.restype = C.c_int
+    L.plb_launch_token_ce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    T = B * S
+    rows = (T + 127) // 128 * 128
+    g = torch.Generator(device=DEV).manual_seed(7)
+    logits = torch.randn(rows, ldd, device=DEV, generator=g) * 3.0
+    tgt = torch.randint(0, NT, (T,), device=DEV, generator=g)
+    lengths = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=DEV)
+    loss_rows = torch.full((rows,), 7.0, device=DEV)
+    dl = torch.full((rows, ldd), 3.0, dtype=torch.bfloat16, device=DEV)
+    rc = L.plb_launch_token_ce(logits.data_ptr(), ldd, NT, tgt.data_ptr(), None if lengths is None else lengths.data_ptr(),
+                               B, S, rows, loss_rows.data_ptr(), dl.data_ptr(), ldd, stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ln = torch.tensor(lens if lens is not None else [S] * B, device=DEV)
+    pos = torch.arange(S, device=DEV)[None, :].expand(B, S)
+    valid = (pos < ln[:, None]).reshape(-1)
+    w = (1.0 / (B * ln.float()))[:, None].expand(B, S).reshape(-1)
+    x = logits[:T, :NT].double()
+    lse = torch.logsumexp(x, -1)
+    want_loss = torch.where(valid, w.double() * (lse - x[torch.arange(T), tgt]), torch.zeros_like(lse))
+    assert torch.allclose(loss_rows[:T].double(), want_loss, rtol=1e-5, atol=1e-7)
+    assert (loss_rows[T:] == 0).all()
+    p = torch.softmax(x, -1)
+    p[torch.arange(T), tgt] -= 1.0
+    want = (p * w.double()[:, None]) * valid[:, None]
+    got = dl[:T, :NT].double()
+    assert rel_l2(got.float(), want.float()) < 4e-3                     # one bf16 rounding
+    assert (dl[:T, NT:] == 0).all() and (dl[T:] == 0).all() and (dl[:T][~valid] == 0).all()
