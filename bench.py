@@ -206,11 +206,11 @@ def main():
         # process slow for some hundred milliseconds — measured: 12.4 instead of 10.8 ms/step over the 25 steps
         # that follow it, at world size 1 — which has nothing to do with the steady state being measured.
         # Settle untimed (every collective type the loop uses has then run once, too), then do the W warm-up steps.
+        # A FIXED number of steps: every step holds a collective, so all ranks must run the same count.
         sync_all()
-        t_settle = time.perf_counter()
-        while time.perf_counter() - t_settle < 1.5:
+        for _ in range(120):
             trainer.step(batch)
-            torch.cuda.synchronize()
+        sync_all()
     for _ in range(args.warmup):
         trainer.step(batch)
     sync_all()
