@@ -283,3 +283,36 @@ def test_training_memorises_a_fixed_batch():
     assert np.isfinite(losses).all()
     assert losses[0] > 4.5 and losses[-1] < 0.5 * losses[0], (losses[0], losses[-1])
     assert bool(torch.isfinite(tr.engine.params).all().item())
+
+
+def test_full_size_properties():
+    """BASELINE configs[1] at full size (768/12, batch 32 x 512), where the fp32 oracle would take minutes: the
+    domain's size-independent properties. (1) two runs are bitwise identical; (2) the loss is the mean of the
+    per-sample losses, so loss(batch) = mean of loss(quarter batches) and the gradients are the mean of the quarter
+    gradients (linearity of the backward); (3) permuting the samples changes nothing but summation order."""
+    pcfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                                   max_position_embeddings=512, num_hidden_layers=12)
+    sd = plbert_amd.deterministic_state_dict(pcfg, 188, seed=17)
+    labels, masked, lengths, idx = plbert_amd.synthetic_batch(32, 512, seed=4242)
+    eng = HipEngine(pcfg, 188, 0, max_batch=32, max_seq=512)
+    eng.load_state_dict(sd)
+
+    def run(sel):
+        off, flat = plbert_amd.masked_indices_to_csr([idx[i] for i in sel])
+        loss = eng.loss_fwd_bwd(masked[sel], labels[sel], None, off, flat, int(off[-1]))
+        torch.cuda.synchronize()
+        return float(loss.item()), eng.grads[: eng.trainable].clone()
+
+    full = list(range(32))
+    l1, g1 = run(full)
+    l2, g2 = run(full)
+    assert l1 == l2 and torch.equal(g1, g2)                                   # (1) reproducible bit for bit
+    assert abs(l1 - np.log(188)) < 0.5                                        # random weights: near-uniform predictions
+    quarters = [run(list(range(q * 8, q * 8 + 8))) for q in range(4)]
+    assert abs(l1 - np.mean([q[0] for q in quarters])) / l1 < 2e-4            # (2) loss is a mean over samples
+    gq = torch.stack([q[1] for q in quarters]).mean(0)
+    assert rel_l2(g1.cpu(), gq.cpu()) < 2e-2                                  # bf16 dY/X stashes, different row splits
+    perm = np.random.RandomState(1).permutation(32).tolist()
+    l3, g3 = run(perm)
+    assert abs(l3 - l1) / l1 < 2e-5
+    assert rel_l2(g3.cpu(), g1.cpu()) < 1e-2                                  # (3) order of summation only
