@@ -74,6 +74,8 @@ class PlbGemmNT(C.Structure):
         ("bias", C.c_void_p), ("res", C.c_void_p), ("ldr", C.c_int), ("aux", C.c_void_p), ("ldaux", C.c_int),
         ("C", C.c_void_p), ("ldc", C.c_int), ("C2", C.c_void_p), ("ldc2", C.c_int), ("Cf", C.c_void_p), ("ldcf", C.c_int),
         ("colpart", C.c_void_p),
+        ("ce_cols", C.c_int), ("ce_tgt", C.c_void_p), ("ce_pmax", C.c_void_p), ("ce_psum", C.c_void_p),
+        ("ce_tlogit", C.c_void_p), ("ce_lse", C.c_void_p), ("ce_w", C.c_void_p),
     ]
 
 

@@ -41,7 +41,7 @@ std::vector<hipEvent_t> g_pool;
 const char* const kClassNames[PLB_K_NCLASS] = {
     "gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32", "gemm_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv",
     "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "reduce_slabs", "gather_scatter_rows", "cross_entropy",
-    "adamw", "cast_transpose", "token_ce"};
+    "adamw", "cast_transpose", "token_ce", "gemm_nt_ce"};
 hipEvent_t prof_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
@@ -109,7 +109,8 @@ struct PlbEngine {
   int64_t slab2_floats;
   // token (grapheme) head training: padded copies and the [Tp][NTp] logit / gradient images (NT > 0 only)
   int NTp = 0;
-  int64_t o_bt = 0, o_wtT = 0, o_tlog = 0, o_tdl = 0, o_tlrows = 0, o_tscr = 0, o_tgrad = 0, o_tloss = 0;
+  int64_t o_bt = 0, o_wtT = 0, o_tdl = 0, o_tlrows = 0, o_tscr = 0, o_tgrad = 0, o_tloss = 0;
+  int64_t o_tpmax = 0, o_tpsum = 0, o_ttl = 0, o_tlse = 0, o_tw = 0, o_ttgt = 0, o_tcolp = 0;
   bool tok_pad_zeroed = false;  // pad columns of the transposed copy are zeroed once
   bool tok_grads_live = false;  // the last loss call produced token-head gradients (AdamW then steps them)
   // side stream: the tail of the backward (embedding chain, bias / LayerNorm column sums) runs beside the
@@ -129,6 +130,8 @@ struct PlbEngine {
   float* par(int which) const { return params + poff[which]; }
   float* grd(int which) const { return grads + poff[which]; }
 };
+
+extern "C" int plb_launch_gemm_nt_big(const PlbGemmNT* p, int tile, int act, int out_f32, hipStream_t stream);
 
 static void layout_params(PlbEngine* e) {
   const int64_t V = e->V, E = e->E, H = e->H, I = e->I, P = e->P, NP = e->NP, NT = e->NT;
@@ -275,10 +278,14 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
     e->NTp = (int)NTp;
     e->o_bt = cv.take(NTp * 4);
     e->o_wtT = cv.take(rup(H, 128) * NTp * 2);
-    e->o_tlog = cv.take(Tp * NTp * 4);
     e->o_tdl = cv.take(Tp * NTp * 2);
     e->o_tlrows = cv.take(Tp * 4);
     e->o_tscr = cv.take(32 * NTp * 4);
+    e->o_tpmax = cv.take(Tp * (NTp / 256) * 4);
+    e->o_tpsum = cv.take(Tp * (NTp / 256) * 4);
+    e->o_ttl = cv.take(Tp * 4); e->o_tlse = cv.take(Tp * 4); e->o_tw = cv.take(Tp * 4);
+    e->o_ttgt = cv.take(Tp * 8);
+    e->o_tcolp = cv.take(2 * (Tp / 128) * NTp * 4);
     e->o_tgrad = cv.take(NTp * H * 4);
     e->o_tloss = cv.take(256);
   }
@@ -554,27 +561,45 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
   }
   if (loss_parts) HIPTRY(hipMemcpyAsync(loss_parts, loss, sizeof(float), hipMemcpyDeviceToDevice, s));
 
-  // ---- token (grapheme) head over every valid position: logits, CE rows, head gradients, dH -----------------
-  // The whole [Tp][NTp] logit image is materialised (4.2 GB fp32 + 2.1 GB bf16 gradient at 16384 x 64000: a
-  // small part of 288 GB), so the three GEMMs run on the pipeline kernels with K or N = NTp in one launch each.
+  // ---- token (grapheme) head over every valid position: fused GEMM + cross-entropy, head gradients, dH ------------
+  // The fp32 logits are never stored. Pass 1 computes them tile by tile and keeps, per row and 256-column tile, the
+  // maximum and the sum of exponentials (+ the target logit); a small kernel merges those into the row's
+  // log-sum-exp, weight and loss; pass 2 recomputes the logits and writes the gradient (softmax - onehot) * w in
+  // bf16 [Tp][NTp] (2.1 GB at 16384 x 64000), the operand of dWt = dlogits^T · H and dH = dlogits · Wt, and the
+  // column-sum partials that give the bias gradient.
   if (token_targets) {
     const int NT = e->NT, NTp = e->NTp;
-    float* tlog = e->at<float>(e->o_tlog);
+    const int tile = (Tp % 256 == 0) ? 256 : 1256;          // 256x256 or 128x256: both 256 columns wide
+    const int ntile = NTp / 256, cprows = tile == 256 ? 2 * (int)(Tp / 256) : 2 * (int)(Tp / 128);
     bf16_t* tdl = e->at<bf16_t>(e->o_tdl);
     float* tlrows = e->at<float>(e->o_tlrows);
     float* tloss = e->at<float>(e->o_tloss);
+    int64_t* ttgt = e->at<int64_t>(e->o_ttgt);
+    HIPTRY(hipMemcpyAsync(ttgt, token_targets, (size_t)T * 8, hipMemcpyDeviceToDevice, s));
+    if (Tp > T) HIPTRY(hipMemsetAsync(ttgt + T, 0, (size_t)(Tp - T) * 8, s));
     memset(&g, 0, sizeof(g));
     g.A = xL; g.lda = H; g.B = e->wbf(PLB_TOK_W); g.ldb = H; g.M = (int)Tp; g.N = NTp; g.K = H; g.Mstore = (int)Tp;
-    g.bias = e->at<float>(e->o_bt); g.Cf = tlog; g.ldcf = NTp;
-    TRY(plb_launch_gemm_nt(&g, 0, 1, s));
-    TRY(plb_launch_token_ce(tlog, NTp, NT, token_targets, lengths, B, S, (int)Tp, tlrows, tdl, NTp, s));
+    g.bias = e->at<float>(e->o_bt);
+    g.ce_cols = NT; g.ce_tgt = ttgt;
+    g.ce_pmax = e->at<float>(e->o_tpmax); g.ce_psum = e->at<float>(e->o_tpsum); g.ce_tlogit = e->at<float>(e->o_ttl);
+    const double ce_flops = 2.0 * (double)Tp * NTp * H;
+    int tok = plb_prof_begin(PLB_K_GEMM_NT_CE, s, ce_flops, 0.0);
+    TRY(plb_launch_gemm_nt_big(&g, tile, 3, 0, s));
+    plb_prof_end(tok, s);
+    TRY(plb_launch_token_ce_combine(g.ce_pmax, g.ce_psum, ntile, g.ce_tlogit, lengths, B, S, (int)Tp,
+                                    e->at<float>(e->o_tlse), e->at<float>(e->o_tw), tlrows, s));
     TRY(plb_launch_sum_rows(tlrows, T, tloss, s));
     TRY(plb_launch_add_scalar(loss, loss, tloss, s));
     if (loss_parts) HIPTRY(hipMemcpyAsync(loss_parts + 1, tloss, sizeof(float), hipMemcpyDeviceToDevice, s));
+    g.ce_lse = e->at<float>(e->o_tlse); g.ce_w = e->at<float>(e->o_tw);
+    g.C = tdl; g.ldc = NTp; g.colpart = e->at<float>(e->o_tcolp);
+    tok = plb_prof_begin(PLB_K_GEMM_NT_CE, s, ce_flops, 0.0);
+    TRY(plb_launch_gemm_nt_big(&g, tile, 4, 0, s));
+    plb_prof_end(tok, s);
+    TRY(plb_launch_colsum(g.colpart, 0, (size_t)cprows, NTp, NTp, e->grd(PLB_TOK_B), NT, 0, e->at<float>(e->o_tscr), 1, s));
     float* gw = NTp == NT ? e->grd(PLB_TOK_W) : e->at<float>(e->o_tgrad);
     if (weight_grad(e, tdl, NTp, NTp, xL, H, Tp, NTp, H, gw, s)) return 1;
     if (NTp != NT) HIPTRY(hipMemcpyAsync(e->grd(PLB_TOK_W), gw, (size_t)NT * H * 4, hipMemcpyDeviceToDevice, s));
-    TRY(plb_launch_colsum(tdl, 1, (size_t)Tp, NTp, NTp, e->grd(PLB_TOK_B), NT, 0, e->at<float>(e->o_tscr), 32, s));
     // dH += dlogits · Wt, on top of the scattered phoneme-head rows (in place: a tile reads its residual
     // before its own stores)
     memset(&g, 0, sizeof(g));

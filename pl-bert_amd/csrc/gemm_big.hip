@@ -406,6 +406,68 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
                           : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   const int ncol0 = bn * TN + wn * 32 + fq * 4;
+  if constexpr (ACT == 3) {
+    // Fused GEMM + cross-entropy, pass 1: nothing is stored but, per row, the maximum and the sum of
+    // exp(logit - maximum) over this tile's real classes, and the logit of the row's target class when it lies in
+    // this tile. A row's 256 columns sit in 4 lanes (fq) of 4 waves (wn): shuffles, then a [row][wn] LDS table.
+    float* const stat = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mh = 0; mh < NAH; ++mh)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        const int lrow = mh * 128 + wm * 64 + mi * 16 + frow;
+        const int m = bm * TM + lrow;
+        const int tg = (int)p.ce_tgt[m];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            f32x4& v = acc[mh][mi][nh][ni];
+            const int n0 = ncol0 + nh * 128 + ni * 16;
+            v[0] += bz[nh][ni].x; v[1] += bz[nh][ni].y; v[2] += bz[nh][ni].z; v[3] += bz[nh][ni].w;
+            if ((unsigned)(tg - n0) < 4u) p.ce_tlogit[m] = v[tg - n0];
+            if (n0 + 3 >= p.ce_cols) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = (n0 + r < p.ce_cols) ? v[r] : -INFINITY;
+            }
+            mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+          }
+        float sm = 0.f;
+        if (mx > -INFINITY) {
+#pragma unroll
+          for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const f32x4 v = acc[mh][mi][nh][ni];
+              sm += (__expf(v[0] - mx) + __expf(v[1] - mx)) + (__expf(v[2] - mx) + __expf(v[3] - mx));
+            }
+        }
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {  // merge the 4 lanes (fq) that hold the same row
+          const float m2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(sm, o, 64);
+          const float mm = fmaxf(mx, m2);
+          sm = mm > -INFINITY ? sm * __expf(mx - mm) + s2 * __expf(m2 - mm) : 0.f;
+          mx = mm;
+        }
+        if (fq == 0) { stat[(lrow * 4 + wn) * 2] = mx; stat[(lrow * 4 + wn) * 2 + 1] = sm; }
+      }
+    __syncthreads();
+    const int ntile = p.N / TN;
+    for (int r = tid; r < TM; r += 512) {
+      float mx = -INFINITY, sm = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        const float m2 = stat[(r * 4 + w4) * 2], s2 = stat[(r * 4 + w4) * 2 + 1];
+        const float mm = fmaxf(mx, m2);
+        sm = mm > -INFINITY ? sm * __expf(mx - mm) + s2 * __expf(m2 - mm) : 0.f;
+        mx = mm;
+      }
+      p.ce_pmax[(size_t)(bm * TM + r) * ntile + bn] = mx;
+      p.ce_psum[(size_t)(bm * TM + r) * ntile + bn] = sm;
+    }
+    return;
+  }
   uint2 keep[NAH][4][NBH][2];  // ACT == 1: the packed pre-activations, for the second (gelu) image
 #pragma unroll
   for (int mh = 0; mh < NAH; ++mh)
@@ -429,6 +491,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
             ux[nh][ni] = *(const uint2*)(p.aux + (size_t)m * p.ldaux + ncol0 + nh * 128 + ni * 16);
       }
       const bool st = m < p.Mstore;
+      // ACT == 4, fused GEMM + cross-entropy pass 2: the logits are recomputed and leave as the gradient
+      // (softmax - onehot) * w, with the row's log-sum-exp from pass 1; padding columns and rows get 0 (w = 0)
+      float ce_l = 0.f, ce_wt = 0.f;
+      int ce_t = -1;
+      if (ACT == 4) { ce_l = p.ce_lse[m]; ce_wt = p.ce_w[m]; ce_t = (int)p.ce_tgt[m]; }
 #pragma unroll
       for (int nh = 0; nh < NBH; ++nh)
 #pragma unroll
@@ -436,6 +503,14 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
           f32x4 v = acc[mh][mi][nh][ni];
           const int n0 = ncol0 + nh * 128 + ni * 16;
           v[0] += bz[nh][ni].x; v[1] += bz[nh][ni].y; v[2] += bz[nh][ni].z; v[3] += bz[nh][ni].w;
+          if (ACT == 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float gq = (n0 + r < p.ce_cols) ? __expf(v[r] - ce_l) * ce_wt : 0.f;
+              gq -= (n0 + r == ce_t) ? ce_wt : 0.f;
+              v[r] = gq;
+            }
+          }
           if (p.res) {
             v[0] += bf_lo(rr[nh][ni].x); v[1] += bf_hi(rr[nh][ni].x);
             v[2] += bf_lo(rr[nh][ni].y); v[3] += bf_hi(rr[nh][ni].y);
@@ -527,6 +602,15 @@ int launch_big(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {
     hipLaunchKernelGGL((gemm_nt_big_kernel<V, 1, false, PF>), grid, block, 0, stream, *p);
   } else if (act == 2) {
     hipLaunchKernelGGL((gemm_nt_big_kernel<V, 2, false, PF>), grid, block, 0, stream, *p);
+  } else if ((act == 3 || act == 4) && TN == 256) {  // fused GEMM + cross-entropy passes: 256-column tiles only
+    if (!p->ce_tgt || p->ce_cols < 1 || p->ce_cols > p->N) return 1;
+    if (act == 3) {
+      if (!p->ce_pmax || !p->ce_psum || !p->ce_tlogit) return 1;
+      hipLaunchKernelGGL((gemm_nt_big_kernel<V, 3, false, PF>), grid, block, 0, stream, *p);
+    } else {
+      if (!p->ce_lse || !p->ce_w || !p->C) return 1;
+      hipLaunchKernelGGL((gemm_nt_big_kernel<V, 4, false, PF>), grid, block, 0, stream, *p);
+    }
   } else {
     return 1;
   }

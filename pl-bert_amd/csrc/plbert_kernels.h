@@ -12,7 +12,7 @@ extern "C" {
 enum PlbKernelClass {
   PLB_K_GEMM_NT = 0, PLB_K_GEMM_NT_GELU, PLB_K_GEMM_NT_GELUBWD, PLB_K_GEMM_NT_F32, PLB_K_GEMM_TN,
   PLB_K_ATTN_FWD, PLB_K_ATTN_BWD_DQ, PLB_K_ATTN_BWD_DKV, PLB_K_LN_FWD, PLB_K_LN_BWD, PLB_K_EMBED_FWD,
-  PLB_K_EMBED_BWD, PLB_K_COLSUM, PLB_K_REDUCE, PLB_K_ROWS, PLB_K_CE, PLB_K_ADAMW, PLB_K_CAST, PLB_K_TOKEN_CE, PLB_K_NCLASS
+  PLB_K_EMBED_BWD, PLB_K_COLSUM, PLB_K_REDUCE, PLB_K_ROWS, PLB_K_CE, PLB_K_ADAMW, PLB_K_CAST, PLB_K_TOKEN_CE, PLB_K_GEMM_NT_CE, PLB_K_NCLASS
 };
 int plb_prof_begin(int cls, hipStream_t s, double flops, double bytes);
 void plb_prof_end(int tok, hipStream_t s);
@@ -30,6 +30,13 @@ typedef struct {
   bf16_t* C2; int ldc2;         // act==1: gelu_new(u)
   float* Cf; int ldcf;          // out_f32
   float* colpart;               // big-tile kernels only, or null: [2*M/TM][N] partial column sums of the output
+  // fused GEMM + cross-entropy over a wide vocabulary (big-tile kernels, 256-column tiles; act 3 and 4):
+  int ce_cols;                  // real classes: columns >= ce_cols are padding
+  const int64_t* ce_tgt;        // [M] target class of each row
+  float* ce_pmax; float* ce_psum;  // act 3 out: [M][N/256] per-tile row maximum / sum of exp(logit - maximum)
+  float* ce_tlogit;             // act 3 out: [M] logit of the target class
+  const float* ce_lse;          // act 4 in: [M] log-sum-exp of the row
+  const float* ce_w;            // act 4 in: [M] row weight (0 on rows without loss)
 } PlbGemmNT;
 int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream);
 int plb_gemm_nt_colpart_rows(int M, int N, int K);  // rows of colpart written for this shape (0: unsupported)
@@ -121,10 +128,11 @@ int plb_launch_ce_fwd_bwd(const float* logits, int ldl, int V, const int32_t* tg
                           float* loss_rows, bf16_t* dlogits, int ldd, hipStream_t stream);
 // loss[0] = sum(loss_rows[0..n))  (single block, deterministic order)
 int plb_launch_sum_rows(const float* x, int n, float* out, hipStream_t stream);
-// token-head loss rows over a wide vocabulary (oracle.albert_np.token_loss); rows >= B*S, padded positions and
-// columns >= NT of dlogits are zero-filled
-int plb_launch_token_ce(const float* logits, int ldl, int NT, const int64_t* targets, const int32_t* lengths, int B, int S,
-                        int rows, float* loss_rows, bf16_t* dlogits, int ldd, hipStream_t stream);
+// Fused token-head CE, between the two GEMM passes: merge the per-tile (max, sum) of every row into lse, the row
+// weight 1 / (B * len) (0 on padded positions and rows >= B*S) and the weighted loss row.
+int plb_launch_token_ce_combine(const float* pmax, const float* psum, int ntiles, const float* tlogit,
+                                const int32_t* lengths, int B, int S, int rows, float* lse, float* w, float* loss_rows,
+                                hipStream_t stream);
 int plb_launch_add_scalar(float* out, const float* a, const float* b, hipStream_t stream);
 
 // Device-side word masking (mask.hip): labels [B,S] -> masked [B,S], counts [B], idx_padded [B,S],

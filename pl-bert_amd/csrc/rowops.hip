@@ -465,56 +465,31 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* logits, int ldl, i
     *(uint2*)(dlogits + (size_t)r * ldd + c) = o;
   }
 }
-// Token-head loss rows (wide vocabulary): one workgroup per token row t = b*S + s, fp32 logits [rows][ldl],
-// NT real classes, ldd >= NT gradient columns. Loss of oracle.albert_np.token_loss: per-sample mean CE over
-// the valid positions, mean over the B samples -> row weight 1 / (B * len_b); padded positions, rows >= T
-// and columns >= NT get a zero gradient (they are operands of the GEMMs that follow).
-// Pass 1 keeps a running (max, sum) per thread over 16-B chunks, pass 2 re-reads the row (256 KiB at 64 k
-// classes: L2-resident) and writes (softmax - onehot) * w in bf16.
-__global__ __launch_bounds__(256) void token_ce_kernel(const float* logits, int ldl, int NT, const int64_t* targets,
-                                                       const int32_t* lengths, int B, int S, int T, float* loss_rows,
-                                                       bf16_t* dlogits, int ldd) {
-  __shared__ float red[2][4];
-  const int t = blockIdx.x, tid = threadIdx.x;
-  bf16_t* drow = dlogits + (size_t)t * ldd;
-  const int b = t / S, sp = t - b * S;
+// Fused token-head CE, between its two GEMM passes: one wave per row merges the per-tile (max, sum) pairs.
+__global__ __launch_bounds__(256) void token_ce_combine_kernel(const float* pmax, const float* psum, int ntiles,
+                                                               const float* tlogit, const int32_t* lengths, int B, int S,
+                                                               int rows, float* lse, float* w, float* loss_rows) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= rows) return;
+  const int T = B * S, b = t / S, sp = t - b * S;
   int len = S;
   if (t < T && lengths) { len = lengths[b]; len = len < 1 ? 1 : (len > S ? S : len); }
   if (t >= T || sp >= len) {
-    for (int c = tid * 8; c < ldd; c += 2048) *(uint4*)(drow + c) = make_uint4(0, 0, 0, 0);
-    if (tid == 0) loss_rows[t] = 0.f;
+    if (lane == 0) { lse[t] = 0.f; w[t] = 0.f; loss_rows[t] = 0.f; }
     return;
   }
-  const float* row = logits + (size_t)t * ldl;
   float m = -INFINITY, l = 0.f;
-  for (int c = tid * 4; c < NT; c += 1024) {
-    const float4 v = *(const float4*)(row + c);
-    const float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-    if (mx > m) { l *= __expf(m - mx); m = mx; }
-    l += (__expf(v.x - m) + __expf(v.y - m)) + (__expf(v.z - m) + __expf(v.w - m));
+  for (int i = lane; i < ntiles; i += 64) {
+    const float pm = pmax[(size_t)t * ntiles + i], ps = psum[(size_t)t * ntiles + i];
+    if (pm > m) { l *= __expf(m - pm); m = pm; }
+    l += ps * __expf(pm - m);
   }
-  const float wm = wave_max(m);
-  l = wave_sum(m == -INFINITY ? 0.f : l * __expf(m - wm));   // a thread (or a whole wave) may have seen no chunk
-  if ((tid & 63) == 0) { red[0][tid >> 6] = wm; red[1][tid >> 6] = l; }
-  __syncthreads();
-  const float M = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-  const float Lsum = red[1][0] * __expf(red[0][0] - M) + red[1][1] * __expf(red[0][1] - M) +
-                     red[1][2] * __expf(red[0][2] - M) + red[1][3] * __expf(red[0][3] - M);
-  const int tg = (int)targets[t];
-  const float w = 1.0f / ((float)B * (float)len);
-  if (tid == 0) loss_rows[t] = w * (M + __logf(Lsum) - row[tg]);
-  const float inv = w / Lsum;
-  for (int c = tid * 4; c < ldd; c += 1024) {
-    uint2 o = make_uint2(0, 0);
-    if (c < NT) {
-      const float4 v = *(const float4*)(row + c);
-      float g0 = __expf(v.x - M) * inv, g1 = __expf(v.y - M) * inv, g2 = __expf(v.z - M) * inv, g3 = __expf(v.w - M) * inv;
-      if ((unsigned)(tg - c) < 4u) {
-        g0 -= (tg == c) ? w : 0.f; g1 -= (tg == c + 1) ? w : 0.f; g2 -= (tg == c + 2) ? w : 0.f; g3 -= (tg == c + 3) ? w : 0.f;
-      }
-      o.x = pack_bf2(g0, g1); o.y = pack_bf2(g2, g3);
-    }
-    *(uint2*)(drow + c) = o;
+  const float M = wave_max(m);
+  l = wave_sum(m == -INFINITY ? 0.f : l * __expf(m - M));
+  if (lane == 0) {
+    const float ls = M + __logf(l), wt = 1.0f / ((float)B * (float)len);
+    lse[t] = ls; w[t] = wt; loss_rows[t] = wt * (ls - tlogit[t]);
   }
 }
 __global__ void add_scalar_kernel(float* out, const float* a, const float* b) { out[0] = a[0] + b[0]; }
@@ -681,12 +656,13 @@ extern "C" int plb_launch_ce_fwd_bwd(const float* logits, int ldl, int V, const 
                      dlogits, ldd);
   return LAUNCH_OK();
 }
-extern "C" int plb_launch_token_ce(const float* logits, int ldl, int NT, const int64_t* targets, const int32_t* lengths,
-                                   int B, int S, int rows, float* loss_rows, bf16_t* dlogits, int ldd, hipStream_t stream) {
-  if (NT % 4 || ldl % 4 || ldd % 8 || ldd < NT || ldl < NT || rows < B * S) return 1;
-  ProfScope ps(PLB_K_TOKEN_CE, stream, 0, (double)B * S * (8.0 * NT + 2.0 * ldd));
-  hipLaunchKernelGGL(token_ce_kernel, dim3(rows), dim3(256), 0, stream, logits, ldl, NT, targets, lengths, B, S, B * S,
-                     loss_rows, dlogits, ldd);
+extern "C" int plb_launch_token_ce_combine(const float* pmax, const float* psum, int ntiles, const float* tlogit,
+                                           const int32_t* lengths, int B, int S, int rows, float* lse, float* w,
+                                           float* loss_rows, hipStream_t stream) {
+  if (ntiles < 1 || rows < B * S) return 1;
+  ProfScope ps(PLB_K_TOKEN_CE, stream, 0, (double)rows * ntiles * 8.0);
+  hipLaunchKernelGGL(token_ce_combine_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, pmax, psum, ntiles, tlogit, lengths,
+                     B, S, rows, lse, w, loss_rows);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_add_scalar(float* out, const float* a, const float* b, hipStream_t stream) {

@@ -202,38 +202,56 @@ def test_colsum():
     assert rel_l2(out, x[:, : N - 4].float().sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("NT,ldd,B,S,lens", [(1000, 1024, 2, 24, [24, 7]), (40, 256, 3, 5, None), (4096, 4096, 1, 130, [77])])
-def test_token_ce_rows(NT, ldd, B, S, lens):
-    """Wide-vocabulary CE rows against torch: loss rows with weight 1 / (B * len), gradient (softmax - onehot) * w in
-    bf16, zeros on padded positions, on rows >= B*S and on columns >= NT."""
+@pytest.mark.parametrize("NT,B,S,lens,tile", [(1000, 2, 64, [64, 7], 1256), (256, 2, 128, None, 256), (4100, 1, 130, [77], 1256)])
+def test_fused_gemm_cross_entropy_passes(NT, B, S, lens, tile):
+    """The two GEMM passes of the fused token-head CE + the merge kernel against torch: loss rows with weight
+    1 / (B * len), gradient (softmax - onehot) * w in bf16, zeros on padded positions, on rows >= B*S and on columns
+    >= NT, and the column-sum partials (bias gradient) of the gradient as stored."""
     L = _lib.lib()
-    L.plb_launch_token_ce.restype = C.c_int
-    L.plb_launch_token_ce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
-                                      C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
-    T = B * S
-    rows = (T + 127) // 128 * 128
-    g = torch.Generator(device=DEV).manual_seed(7)
-    logits = torch.randn(rows, ldd, device=DEV, generator=g) * 3.0
-    tgt = torch.randint(0, NT, (T,), device=DEV, generator=g)
+    L.plb_launch_gemm_nt_big.restype = C.c_int
+    L.plb_launch_gemm_nt_big.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.plb_launch_token_ce_combine.restype = C.c_int
+    L.plb_launch_token_ce_combine.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                              C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    T, H = B * S, 128
+    Tp = (T + 255) // 256 * 256 if tile == 256 else (T + 127) // 128 * 128
+    NTp = (NT + 255) // 256 * 256
+    g = torch.Generator(device=DEV).manual_seed(11)
+    A = (torch.randn(Tp, H, device=DEV, generator=g)).to(torch.bfloat16)
+    W = (torch.randn(NTp, H, device=DEV, generator=g) * 0.3).to(torch.bfloat16)
+    bias = torch.zeros(NTp, device=DEV)
+    bias[:NT] = torch.randn(NT, device=DEV, generator=g)
+    tgt = torch.zeros(Tp, dtype=torch.int64, device=DEV)
+    tgt[:T] = torch.randint(0, NT, (T,), device=DEV, generator=g)
+    ntile = NTp // 256
+    pmax, psum = torch.empty(Tp, ntile, device=DEV), torch.empty(Tp, ntile, device=DEV)
+    tl, lse, w, lrows = (torch.full((Tp,), 7.0, device=DEV) for _ in range(4))
+    dl = torch.full((Tp, NTp), 3.0, dtype=torch.bfloat16, device=DEV)
+    cprows = 2 * (Tp // 256) if tile == 256 else 2 * (Tp // 128)
+    colp = torch.empty(cprows, NTp, device=DEV)
     lengths = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=DEV)
-    loss_rows = torch.full((rows,), 7.0, device=DEV)
-    dl = torch.full((rows, ldd), 3.0, dtype=torch.bfloat16, device=DEV)
-    rc = L.plb_launch_token_ce(logits.data_ptr(), ldd, NT, tgt.data_ptr(), None if lengths is None else lengths.data_ptr(),
-                               B, S, rows, loss_rows.data_ptr(), dl.data_ptr(), ldd, stream())
-    assert rc == 0
+    p = _lib.PlbGemmNT()
+    p.A, p.lda, p.B, p.ldb, p.M, p.N, p.K, p.Mstore = A.data_ptr(), H, W.data_ptr(), H, Tp, NTp, H, Tp
+    p.bias, p.ce_cols, p.ce_tgt = bias.data_ptr(), NT, tgt.data_ptr()
+    p.ce_pmax, p.ce_psum, p.ce_tlogit = pmax.data_ptr(), psum.data_ptr(), tl.data_ptr()
+    assert L.plb_launch_gemm_nt_big(C.byref(p), tile, 3, 0, stream()) == 0
+    assert L.plb_launch_token_ce_combine(pmax.data_ptr(), psum.data_ptr(), ntile, tl.data_ptr(),
+                                         None if lengths is None else lengths.data_ptr(), B, S, Tp, lse.data_ptr(),
+                                         w.data_ptr(), lrows.data_ptr(), stream()) == 0
+    p.ce_lse, p.ce_w, p.C, p.ldc, p.colpart = lse.data_ptr(), w.data_ptr(), dl.data_ptr(), NTp, colp.data_ptr()
+    assert L.plb_launch_gemm_nt_big(C.byref(p), tile, 4, 0, stream()) == 0
     torch.cuda.synchronize()
     ln = torch.tensor(lens if lens is not None else [S] * B, device=DEV)
-    pos = torch.arange(S, device=DEV)[None, :].expand(B, S)
-    valid = (pos < ln[:, None]).reshape(-1)
-    w = (1.0 / (B * ln.float()))[:, None].expand(B, S).reshape(-1)
-    x = logits[:T, :NT].double()
-    lse = torch.logsumexp(x, -1)
-    want_loss = torch.where(valid, w.double() * (lse - x[torch.arange(T), tgt]), torch.zeros_like(lse))
-    assert torch.allclose(loss_rows[:T].double(), want_loss, rtol=1e-5, atol=1e-7)
-    assert (loss_rows[T:] == 0).all()
-    p = torch.softmax(x, -1)
-    p[torch.arange(T), tgt] -= 1.0
-    want = (p * w.double()[:, None]) * valid[:, None]
-    got = dl[:T, :NT].double()
-    assert rel_l2(got.float(), want.float()) < 4e-3                     # one bf16 rounding
+    valid = (torch.arange(S, device=DEV)[None, :] < ln[:, None]).reshape(-1)
+    wr = (1.0 / (B * ln.double()))[:, None].expand(B, S).reshape(-1)
+    x = (A[:T].double() @ W[:NT].double().T) + bias[:NT].double()
+    ref_lse = torch.logsumexp(x, -1)
+    want_loss = torch.where(valid, wr * (ref_lse - x[torch.arange(T), tgt[:T]]), torch.zeros_like(ref_lse))
+    assert torch.allclose(lrows[:T].double(), want_loss, rtol=2e-5, atol=1e-7)
+    assert (lrows[T:] == 0).all() and (w[T:] == 0).all()
+    pr = torch.softmax(x, -1)
+    pr[torch.arange(T), tgt[:T]] -= 1.0
+    want = pr * wr[:, None] * valid[:, None]
+    assert rel_l2(dl[:T, :NT].float(), want.float()) < 4e-3                 # one bf16 rounding
     assert (dl[:T, NT:] == 0).all() and (dl[T:] == 0).all() and (dl[:T][~valid] == 0).all()
+    assert rel_l2(colp.sum(0)[:NT], dl[:, :NT].float().sum(0)) < 1e-5        # bias gradient = column sums as stored
