@@ -1,13 +1,16 @@
 #!/bin/bash
-# usage: tools/pmc.sh <outname> <counters...> -- <program args...>   (run on the GPU box)
+# usage: tools/pmc.sh <outname> <counters...> -- <script.py> <args...>   (run on the GPU box, from the repo root;
+# the script path is taken relative to the repo root: rocprofv3 itself runs from /tmp)
 name=$1; shift
 ctrs=()
 while [ "$1" != "--" ]; do ctrs+=("$1"); shift; done
 shift
 R=$PWD
+prog=$1; shift
+case "$prog" in /*) ;; *) prog="$R/$prog" ;; esac
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/pmc
-cd /tmp && timeout -k 5 150 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d $R/gpurun_out/pmc -o $name -- python3 "$@" > $R/gpurun_out/pmc/$name.log 2>&1
+cd /tmp && timeout -k 5 150 rocprofv3 --pmc "${ctrs[@]}" --kernel-trace --output-format csv -d $R/gpurun_out/pmc -o $name -- python3 "$prog" "$@" > $R/gpurun_out/pmc/$name.log 2>&1
 echo "rocprof rc=$?"
 cd $R
 python3 - <<PY
