@@ -13,7 +13,6 @@ from dataclasses import dataclass
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from .data import masked_indices_to_csr
 from .dist import GradReducer

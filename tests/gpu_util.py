@@ -1,7 +1,6 @@
 """Helpers shared by the -m gpu tests: raw launches through the C ABI with torch tensors as buffers."""
 import ctypes as C
 
-import numpy as np
 import torch
 
 from plbert_amd import _lib

@@ -3,12 +3,11 @@ PyTorch fp32 reference of the same op on the same bf16-rounded inputs."""
 import ctypes as C
 import math
 
-import numpy as np
 import pytest
 import torch
 
 from plbert_amd import _lib
-from gpu_util import attn_args, bf16_round, gemm_nt, gemm_tn, rel_l2, stream, torch_attention
+from gpu_util import attn_args, gemm_nt, gemm_tn, rel_l2, stream, torch_attention
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"

@@ -1,5 +1,4 @@
 """Masking / index path: bit-exact against vectors captured from the reference's dataloader.py."""
-import random
 
 import numpy as np
 import torch
