@@ -2,7 +2,7 @@
  *
  * The reference (Fadi987/PL-BERT) has no FFI: its boundary for this path is a Python nn.Module
  * contract.  Each entry point below names the reference interface it stands in
- * for; the Python host in pl-bert_amd/ (model.py, engine.py) binds them with ctypes and mirrors the
+ * for; the Python host in plbert_amd/ (model.py, engine.py) binds them with ctypes and mirrors the
  * reference classes on top.  Plain pointers and sizes only: device pointers are raw HBM addresses
  * (any allocator — the Python host passes torch tensors' data_ptr()), `stream` is a hipStream_t
  * passed as void* (NULL = the legacy default stream).  Every call is asynchronous on `stream`
@@ -140,7 +140,7 @@ int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, float eps, 
  * then mask with phoneme_mask_prob / replace from the sample's own phonemes with replace_prob / keep),
  * separators never masked or indexed, but counter-based Philox randomness keyed by (seed, step, sample,
  * word) instead of the reference's global NumPy/Python streams — distribution-matched, NOT bit-exact
- * (the bit-exact path is the host one in pl-bert_amd/data.py). Needs no engine.
+ * (the bit-exact path is the host one in plbert_amd/data.py). Needs no engine.
  * labels int64 [B,S] (separator id sep_id between words, positions >= lengths[b] ignored); outputs:
  * masked int64 [B,S], idx_offsets int32 [B+1], idx_flat int32 [up to B*S], scratch int32 [B + B*S].
  * S <= 512, B <= 1024. The total count is idx_offsets[B] (read it back before plb_loss_fwd_bwd). */

@@ -1,7 +1,7 @@
 """CPU oracle for the PL-BERT masked-phoneme pre-training step.  TEST INFRASTRUCTURE ONLY.
 
 This file is the checker, not the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
-``cpu_baseline`` leg of ``bench.py`` may import it.  The product path (``pl-bert_amd/``) never
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product path (``plbert_amd/``) never
 routes through it and fails loudly when the HIP library is missing.
 
 It restates, in plain numpy, the arithmetic of the reference hot path:

@@ -2,7 +2,7 @@
 //
 // The reference masks on the host, one Python string operation per word, from NumPy's and Python's
 // global generators (dataloader.py:83-108) — that path is reproduced bit-exactly on the host by
-// pl-bert_amd/data.py. This kernel is the distribution-matched device version for when the input
+// plbert_amd/data.py. This kernel is the distribution-matched device version for when the input
 // pipeline must keep up with the GPUs: same decision tree and probabilities, counter-based
 // Philox4x32-10 randomness keyed by (seed, step, sample, word / position), so a batch is a pure
 // function of its inputs (reproducible, order-independent), but NOT the reference's bit stream.

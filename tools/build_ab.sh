@@ -1,10 +1,10 @@
 #!/bin/bash
-# Snapshot the CURRENT sources as an A/B library: pl-bert_amd/build/ab/lib_<name>.so, linked -Bsymbolic so its
+# Snapshot the CURRENT sources as an A/B library: plbert_amd/build/ab/lib_<name>.so, linked -Bsymbolic so its
 # internal calls bind to itself when it is loaded beside the product build (tools/gemm_bench.py --libs,
 # tools/ln_bench.py --libs). Extra arguments are compile flags for every source (e.g. -DNT_VAR=1).
 set -e
 cd "$(dirname "$0")/.."
-P=pl-bert_amd
+P=plbert_amd
 O=$P/build/ab/$1
 mkdir -p $O
 for f in gemm.hip gemm_big.hip attn.hip rowops.hip mask.hip engine.cpp; do

@@ -4,7 +4,7 @@
 # 8 no K-loop barriers). Run after the normal build; use with PLBERT_HIP_LIB=... tools/gemm_bench.py.
 set -e
 cd "$(dirname "$0")/.."
-P=pl-bert_amd
+P=plbert_amd
 mkdir -p $P/build/dbg
 for n in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DNT_DBG=$n -x hip -c $P/csrc/gemm_big.hip -o $P/build/dbg/gemm_big_$n.o
