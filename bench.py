@@ -2,12 +2,19 @@
 """PL-BERT pre-training hot path on MI355X: phoneme-tokens/s of the full training step.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 works as typed: the parent process (which never touches the GPU) starts N ranks with
+``python -m torch.distributed.run`` and relays rank 0's JSON line; launched under torch.distributed.run
+already (RANK / WORLD_SIZE in the environment) the script is a rank itself.  One rank per GPU; when the node
+has fewer GPUs than ranks (rehearsal on a one-GPU box) the ranks share devices and the exchange falls back to
+gloo — the line then says so in ``comm``.
 
 One step = masked-phoneme forward -> per-sample masked cross-entropy -> backward -> gradient
-all-reduce (N > 1, RCCL) -> AdamW, on one synthetic fixed-length batch per rank that is resident in
-HBM before the timed region (BASELINE.json configs[1]: ALBERT hidden 768 / 12 shared layers / FFN
-2048, seq 512, batch 32 per GPU; weak scaling).  Prints ONE JSON line on rank 0.
+all-reduce (N > 1: RCCL behind the C ABI, issued piecewise inside the backward) -> AdamW, on one synthetic
+fixed-length batch per rank (BASELINE.json configs[1]: ALBERT hidden 768 / 12 shared layers / FFN 2048, seq
+512, batch 32 per GPU; weak scaling).  ``value`` times the step with its batch resident in HBM;
+``staged`` repeats the K steps with a FRESH host batch staged every step (pinned buffers, copy stream,
+double buffered) as a real input pipeline would.  Prints ONE JSON line on rank 0.
 
 roofline: the dominant kernel class of the step, algorithmic FLOPs per launch / average launch
 duration, from per-launch HIP events recorded on the launch stream during a re-run of the same K
@@ -51,9 +58,40 @@ def parse():
                          "of this size, e.g. 64000) instead of the reference's phoneme-only step; a second, "
                          "separately reported workload")
     ap.add_argument("--force-dist", action="store_true",
-                    help="initialise the RCCL process group and run the gradient all-reduce even at world size 1 "
+                    help="create the RCCL communicator and run the gradient all-reduce even at world size 1 "
                          "(rehearses the N>1 code path on a one-GPU box)")
+    ap.add_argument("--comm", choices=["auto", "rccl", "torch"], default="auto",
+                    help="gradient exchange: the engine's own RCCL communicator (C ABI) or torch.distributed")
+    ap.add_argument("--overlap", choices=["auto", "on", "off"], default="auto",
+                    help="piecewise all-reduce inside the backward (on) or one collective after it (off); auto times "
+                         "both during warm-up and keeps the faster")
+    ap.add_argument("--no-staged", action="store_true", help="skip the per-step-staging re-run")
     return ap.parse_args()
+
+
+def launch_ranks(n):
+    """Parent of an N-rank run: start the ranks as a child ``torch.distributed.run`` (this process has made no GPU
+    call and makes none), pass the children's stderr through, relay the single JSON line rank 0 prints."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if line is None:
+        sys.stderr.write(r.stdout)
+        raise SystemExit(r.returncode or 1)
+    print(line, flush=True)
+    raise SystemExit(r.returncode)
 
 
 def cpu_baseline(budget_s):
@@ -119,7 +157,7 @@ def pmc_traffic(cls):
         try:
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                   "--no-roofline", "--no-traffic"]
+                   "--no-roofline", "--no-traffic", "--no-staged"]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -142,8 +180,79 @@ def pmc_traffic(cls):
     return {"bytes": round(fetch + write), "fetch": round(fetch), "write": round(write), "launches_sampled": launches}
 
 
+class StagedFeeder:
+    """Per-step staging of a FRESH host batch: K distinct synthetic batches are generated (and validated — host work a
+    real pipeline does in its loader workers) before the timed region; each step's batch is packed into ONE pinned host
+    buffer and sent with ONE asynchronous copy on a copy stream into one of two device slots, so the copy of step
+    i+1 runs beside the compute of step i; the compute stream only waits for its slot's event."""
+
+    def __init__(self, trainer, n, B, S, seed, torch):
+        import plbert_amd
+        from plbert_amd.train import StagedBatch, validate_batch
+        self.torch, self.trainer, self.B, self.S = torch, trainer, B, S
+        self.StagedBatch = StagedBatch
+        dev = trainer.engine.device
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        self.host, self.meta = [], []
+        cap = 2 * B * S * 8 + (B + 1) * 4 + B * S * 4  # labels | masked | offsets | flat
+        for i in range(n):
+            labels, masked, lengths, idx = plbert_amd.synthetic_batch(B, S, seed=seed + 7919 * (i + 1))
+            validate_batch(labels, masked, lengths, idx, trainer.engine.cfg.vocab_size)
+            off, flat = plbert_amd.masked_indices_to_csr(idx)
+            buf = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            v = buf.numpy()
+            o1, o2, o3 = B * S * 8, 2 * B * S * 8, 2 * B * S * 8 + (B + 1) * 4
+            v[:o1] = np.ascontiguousarray(labels).view(np.uint8).ravel()
+            v[o1:o2] = np.ascontiguousarray(masked).view(np.uint8).ravel()
+            v[o2:o3] = off.view(np.uint8)
+            v[o3:o3 + flat.size * 4] = flat.view(np.uint8)
+            self.host.append(buf)
+            self.meta.append((int(off[-1]), o1, o2, o3))
+        self.slots = [torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)]
+        self.ready = [torch.cuda.Event() for _ in range(2)]
+        self.free = [torch.cuda.Event() for _ in range(2)]
+
+    def send(self, i):
+        t, k = self.torch, i & 1
+        with t.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.free[k])  # the step that last read this slot has finished
+            self.slots[k].copy_(self.host[i % len(self.host)], non_blocking=True)
+            self.ready[k].record(self.copy_stream)
+
+    def batch(self, i):
+        t, k, B, S = self.torch, i & 1, self.B, self.S
+        n, o1, o2, o3 = self.meta[i % len(self.host)]
+        t.cuda.current_stream().wait_event(self.ready[k])
+        d = self.slots[k]
+        return self.StagedBatch(d[o1:o2].view(t.int64).view(B, S), d[:o1].view(t.int64).view(B, S), None,
+                                d[o2:o3].view(t.int32), d[o3:o3 + 4 * n].view(t.int32), n, B * S, None)
+
+    def done(self, i):
+        self.free[i & 1].record(self.torch.cuda.current_stream())
+
+    def run(self, steps):
+        for k in range(2):
+            self.free[k].record(self.torch.cuda.current_stream())
+        self.send(0)
+        loss = None
+        for i in range(steps):
+            if i + 1 < steps:
+                self.send(i + 1)
+            loss = self.trainer.step(self.batch(i))
+            self.done(i)
+        return loss
+
+
+# HBM-bound kernel classes of the step and the roofline they are priced against
+MEMORY_BOUND = ("embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "colsum", "reduce_slabs", "cross_entropy", "adamw",
+                "gather_scatter_rows", "cast_transpose")
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(args.gpus)  # never returns
     # The contract is ONE JSON line on stdout. Native libraries write there too (RCCL prints a version banner
     # when the first communicator is created), so fd 1 points at stderr until the line is printed.
     sys.stdout.flush()
@@ -160,17 +269,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ndev = torch.cuda.device_count()  # does not initialise the GPU
+    shared = world > ndev             # rehearsal: more ranks than GPUs, ranks share devices
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # under torch.distributed.run
     if world > 1 or (launched and args.force_dist):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # nccl == RCCL on ROCm. No device_id: that would create the communicator NOW, and device buffers
-        # allocated after an RCCL communicator exists are slower to use on this stack (measured at world size
-        # 1: 11.3 instead of 10.85 ms/step, with or without collectives in the step). Lazily, the communicator
-        # appears at the first collective — the start-up parameter broadcast, after the engine's allocations.
-        dist.init_process_group("nccl")
+        # torch.distributed is the CONTROL plane only (rendezvous, barriers, the max over ranks of the time): gloo.
+        # The gradient exchange is the engine's own RCCL communicator (plb_comm_init), created after the engine's
+        # buffers exist — device buffers allocated after an RCCL communicator exists are slower to use on this stack
+        # (measured at world size 1: 11.3 instead of 10.85 ms/step).
+        dist.init_process_group("gloo")
+    comm_mode = args.comm
+    if comm_mode == "auto":
+        comm_mode = "torch" if shared else "rccl"
+    force = args.force_dist and not dist.is_initialized()
+    if force:  # single process, no launcher: a one-rank group so the collectives have something to run in
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=0, world_size=1)
 
     if args.model == "large":
         cfg = plbert_amd.AlbertConfig(vocab_size=len(plbert_amd.symbols), hidden_size=1024, num_attention_heads=16,
@@ -186,8 +306,9 @@ def main():
         model_desc = "hidden 768 / 12 shared layers / FFN 2048 / 12 heads"
     B, S = args.batch, args.seq
     trainer = PLBertTrainer(cfg, num_phonemes=len(plbert_amd.symbols), max_batch=B, max_seq=S, lr=7e-5,
-                            device=f"cuda:{local_rank}", seed=0, force_collectives=args.force_dist,
-                            num_tokens=args.num_tokens)
+                            device=f"cuda:{dev_index}", seed=0, force_collectives=args.force_dist,
+                            num_tokens=args.num_tokens, comm=comm_mode, overlap=args.overlap != "off")
+    eng = trainer.engine
     labels, masked, lengths, idx = plbert_amd.synthetic_batch(B, S, seed=1234 + rank)
     token_ids = None
     if args.num_tokens:
@@ -197,34 +318,126 @@ def main():
     batch = trainer.stage_batch(labels, masked, lengths, idx, token_ids=token_ids)  # resident in HBM before timing
 
     def sync_all():
+        torch.cuda.synchronize()
         if dist.is_initialized():
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier()
         torch.cuda.synchronize()
 
-    if dist.is_initialized():
-        # Creating the RCCL communicator (the start-up broadcast above is the first collective) leaves the
-        # process slow for some hundred milliseconds — measured: 12.4 instead of 10.8 ms/step over the 25 steps
-        # that follow it, at world size 1 — which has nothing to do with the steady state being measured.
-        # Settle untimed (every collective type the loop uses has then run once, too), then do the W warm-up steps.
-        # A FIXED number of steps: every step holds a collective, so all ranks must run the same count.
+    def max_over_ranks(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
+    def timed(fn, n):
         sync_all()
-        for _ in range(120):
-            trainer.step(batch)
+        t0 = time.perf_counter()
+        out = fn(n)
         sync_all()
-    for _ in range(args.warmup):
-        trainer.step(batch)
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.step(batch)
-    sync_all()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        return max_over_ranks(time.perf_counter() - t0), out
+
+    def run_steps(n):
+        loss = None
+        for _ in range(n):
+            loss = trainer.step(batch)
+        return loss
+
+    comm_info = {"mode": trainer.comm, "control_plane": "gloo" if dist.is_initialized() else None}
+    ranks_seen = 1
+    if trainer.comm == "rccl":
+        # every rank adds a one through the engine's communicator: the sum is the number of ranks that took part
+        eng.grads.fill_(1.0)
+        eng.set_grad_overlap(False)
+        eng.allreduce_grads()
+        torch.cuda.synchronize()
+        ranks_seen = int(round(float(eng.grads[0].item())))
+        _, w_, ver = eng.comm_info()
+        comm_info.update(rccl_version=ver, world=w_)
+        eng.set_grad_overlap(args.overlap != "off")
+    elif trainer.comm == "torch":
+        t = torch.ones(1, device=eng.device)
+        dist.all_reduce(t)
+        ranks_seen = int(round(float(t.item())))
+        comm_info.update(backend=dist.get_backend(), shared_devices=shared)
+    if trainer.comm != "none":
+        # Creating a communicator leaves the process slow for some hundred milliseconds (measured at world size 1:
+        # 12.4 instead of 10.8 ms/step over the 25 steps that follow it): settle untimed. A FIXED number of steps:
+        # every step holds a collective, so all ranks run the same count.
+        run_steps(60)
+        sync_all()
+    overlap_choice = None
+    if trainer.comm == "rccl":
+        if args.overlap == "auto":  # warm-up doubles as the calibration: time both forms, keep the faster
+            probe = {}
+            for mode in (True, False):
+                eng.set_grad_overlap(mode)
+                run_steps(3)
+                probe[mode], _ = timed(run_steps, max(5, args.warmup))
+            overlap_choice = probe[True] <= probe[False]
+            if world > 1:  # all ranks must agree
+                t = torch.tensor([1.0 if overlap_choice else 0.0])
+                dist.broadcast(t, src=0)
+                overlap_choice = bool(t.item() > 0.5)
+            comm_info["calibration_ms_per_step"] = {"overlap": round(probe[True] / max(5, args.warmup) * 1e3, 3),
+                                                    "serial": round(probe[False] / max(5, args.warmup) * 1e3, 3)}
+        else:
+            overlap_choice = args.overlap == "on"
+        eng.set_grad_overlap(overlap_choice)
+        comm_info["overlap"] = overlap_choice
+    run_steps(args.warmup)
+    dt, loss = timed(run_steps, args.steps)
     loss_val = float(loss.item())
 
+    # ---- the same K steps with a fresh batch staged every step (H2D inside the timed region) -------------------
+    staged = None
+    if not args.no_staged and not args.num_tokens:
+        feeder = StagedFeeder(trainer, min(args.steps, 16), B, S, 99 + rank, torch)
+        feeder.run(2)
+        dts, _ = timed(feeder.run, args.steps)
+        staged = {"ms_per_step": round(dts / args.steps * 1e3, 3),
+                  "value": round(world * B * S * args.steps / dts, 1),
+                  "how": "fresh host batch per step: one pinned buffer, one async copy on a copy stream, two device "
+                         "slots (copy of step i+1 beside compute of step i); batches generated and validated before "
+                         "the timed region"}
+
+    # ---- all-reduce cost: serial collective timed by events; step time with the exchange skipped ---------------
+    if trainer.comm == "rccl" and world >= 1:
+        eng.set_grad_overlap(False)
+        run_steps(2)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        sync_all()
+        for a, b in ev:
+            trainer.loss_and_grads(batch)
+            a.record()
+            eng.allreduce_grads()
+            b.record()
+            trainer.step_count += 1
+            eng.adamw_step(trainer.step_count, trainer.lr, trainer.betas, trainer.eps, trainer.weight_decay, 1.0 / world)
+        sync_all()
+        comm_info["allreduce_ms_per_step_serial"] = round(max_over_ranks(sum(a.elapsed_time(b) for a, b in ev) / len(ev)), 4)
+        eng.set_grad_overlap(True)
+        run_steps(2)
+        t_ov, _ = timed(run_steps, args.steps)
+        eng.set_grad_overlap(False)
+        run_steps(2)
+        t_se, _ = timed(run_steps, args.steps)
+
+        def no_comm(n):  # replicas drift apart from here on: timing only, and nothing after it uses the weights
+            for _ in range(n):
+                trainer.loss_and_grads(batch)
+                trainer.step_count += 1
+                eng.adamw_step(trainer.step_count, trainer.lr, trainer.betas, trainer.eps, trainer.weight_decay, 1.0 / world)
+        eng.comm_destroy()
+        no_comm(2)
+        t_nc, _ = timed(no_comm, args.steps)
+        k = 1e3 / args.steps
+        comm_info.update(step_ms_overlap=round(t_ov * k, 3), step_ms_serial=round(t_se * k, 3),
+                         step_ms_no_exchange=round(t_nc * k, 3),
+                         allreduce_ms_per_step_exposed=round((min(t_ov, t_se) - t_nc) * k, 3))
+        trainer.comm = "none"
+        trainer.reducer.active = False
+        trainer.world = 1
     roofline = None
     if not args.no_roofline:
         _lib.profile_enable(True)
@@ -247,9 +460,17 @@ def main():
                                                sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
                         "_algo_bytes": round(dom["bytes"] / dom["launches"]),
                         "step_mfma_frac": round(flop_per_token * B * S / (total_ms / args.steps * 1e-3) / 1e12
-                                                / MFMA_BF16_PEAK_TFLOPS, 4)}
+                                                / MFMA_BF16_PEAK_TFLOPS, 4),
+                        # north_star: achieved HBM GB/s of the memory-bound kernels against the chip's peak —
+                        # algorithmic bytes of the launches / their HIP-event time (PMC bytes: profiles/)
+                        "memory_bound": [{"kernel": k, "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                          "frac_of_8TBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3),
+                                          "ms_per_step": round(v["ms"] / args.steps, 3),
+                                          "MB_per_step": round(v["bytes"] / args.steps / 1e6, 1)}
+                                         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])
+                                         if k in MEMORY_BOUND and v["ms"] > 0 and v["bytes"] > 0]}
 
-    if roofline is not None and world == 1 and not dist.is_initialized() and not args.no_traffic:
+    if roofline is not None and world == 1 and not dist.is_initialized() and not args.no_traffic and not args.num_tokens:
         t = pmc_traffic(roofline["kernel"])
         if t is not None:
             roofline["traffic"] = t["bytes"]
@@ -275,6 +496,7 @@ def main():
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
             "step_loss": round(loss_val, 5),
             "step_mfma_frac_wall": round(flop_per_token * B * S / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "ranks_seen": ranks_seen, "comm": comm_info, "staged": staged,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
@@ -282,7 +504,7 @@ def main():
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if dist.is_initialized():
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -37,6 +37,9 @@ typedef struct {
   int32_t num_tokens;              /* token_predictor out features, 0 = PhonemeOnlyModel (model.py:11) */
   int32_t max_batch;               /* capacity: largest B accepted by the calls below */
   int32_t max_seq;                 /* capacity: largest S (<= max_position_embeddings) */
+  int32_t inference_only;          /* 1: forward / loss-only use (README.md:91, train.py:288-304 validate): the workspace
+                                      keeps ONE layer's activations instead of all of them, no gradient stash; the
+                                      backward and AdamW entry points then fail. 0: training engine. */
 } PlbConfig;
 
 /* Parameter tensors in flat-buffer order; names follow the reference state_dict.
@@ -107,6 +110,11 @@ int plb_sync_weights(PlbEngine* e, void* stream);
 int plb_forward(PlbEngine* e, const int64_t* ids, const int32_t* lengths, int32_t B, int32_t S, float* hidden,
                 float* phoneme_logits, float* token_logits, void* stream);
 
+/* AlbertModel's pooler_output (modeling_albert.py:403; computed by the reference, never used by its loss):
+ * pooled[b,:] = tanh(pooler.weight · hidden[b,0,:] + pooler.bias); hidden fp32 [B,S,H] (plb_forward's output),
+ * pooled fp32 [B,H]. */
+int plb_pooler(PlbEngine* e, const float* hidden, int32_t B, int32_t S, float* pooled, void* stream);
+
 /* Stands in for process_batch + calculate_phoneme_loss + accelerator.backward (train.py:381-390,
  * 107-131, 356): masked_ids/labels int64 [B,S]; lengths int32 [B]; the per-sample masked index
  * lists as CSR (idx_offsets int32 [B+1], idx_flat int32 [n_masked], positions < lengths[b], unique
@@ -116,6 +124,13 @@ int plb_forward(PlbEngine* e, const int64_t* ids, const int32_t* lengths, int32_
 int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int32_t* lengths,
                      const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked, int32_t B, int32_t S,
                      float* loss, void* stream);
+
+/* Stands in for process_batch under torch.no_grad() — validate() (train.py:288-304): forward + the same loss as
+ * plb_loss_fwd_bwd (or plb_loss_fwd_bwd_dual when token_ids != NULL; loss_parts optional), NO backward: the bound
+ * gradient buffer is not touched, nothing is stashed. Works on training and inference-only engines. */
+int plb_loss_fwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int64_t* token_ids,
+                 const int32_t* lengths, const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked, int32_t B,
+                 int32_t S, float* loss, float* loss_parts, void* stream);
 
 /* Dual-head training step for MultiTaskModel (model.py:5-18: phoneme_predictor + token_predictor) fed by the
  * 4-tuple Collater batch (dataloader.py:200-223: token_ids, labels, masked, lengths, indices). The reference
@@ -134,6 +149,53 @@ int plb_loss_fwd_bwd_dual(PlbEngine* e, const int64_t* masked_ids, const int64_t
  * grad_scale first (1/world_size after a sum all-reduce). Also refreshes the bf16 copies. */
 int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                    float grad_scale, void* stream);
+
+/* The token head (trained by dual-head steps only) keeps its own AdamW step count, as torch keeps one per parameter
+ * (train.py:417-421 saves it in 'optimizer'). Read / restore it around checkpoints. */
+int32_t plb_token_head_steps(const PlbEngine* e);
+int plb_set_token_head_steps(PlbEngine* e, int32_t steps);
+
+/* ---- data-parallel exchange step (train.py:218-221,160-162,356: accelerate -> DDP -> NCCL; here RCCL over xGMI) ----
+ * One process per GPU, one engine per process. Rank 0 calls plb_comm_unique_id and hands the 128 bytes to every rank
+ * over any host channel (the Python host: torch.distributed's store); then every rank calls plb_comm_init (collective,
+ * blocks until all ranks arrived). The library resolves RCCL at run time (the librccl.so.1 already mapped in the
+ * process, else the system one; PLBERT_RCCL_LIB overrides) - it is not linked against it. */
+#define PLB_COMM_ID_BYTES 128
+int plb_comm_unique_id(uint8_t id[PLB_COMM_ID_BYTES]);
+int plb_comm_init(PlbEngine* e, const uint8_t id[PLB_COMM_ID_BYTES], int32_t rank, int32_t world);
+int plb_comm_destroy(PlbEngine* e);
+int plb_comm_info(const PlbEngine* e, int32_t* rank, int32_t* world, int32_t* rccl_version);
+/* DDP's start-up broadcast of rank `root`'s parameters; refreshes the bf16 copies. */
+int plb_broadcast_params(PlbEngine* e, int32_t root, void* stream);
+/* overlap = 1 (default): plb_loss_fwd_bwd[_dual] itself issues the gradient all-reduce, in contiguous pieces of the
+ * flat buffer on the engine's communication stream as each piece becomes final (head gradients at the start of the
+ * backward; the shared layer's weight gradients one by one, each while the next weight-gradient GEMM runs), and
+ * plb_allreduce_grads only joins it. overlap = 0: plb_allreduce_grads performs ONE all-reduce in `stream`. */
+int plb_set_grad_overlap(PlbEngine* e, int32_t overlap);
+/* Sum all-reduce of every gradient the last loss call produced (the trainable range; plus the token head after a
+ * dual-head step) over the ranks of the communicator; plb_adamw_step's grad_scale = 1/world turns it into DDP's mean.
+ * After the call returns the reduced gradients are ordered before later work on `stream`. No communicator: no-op. */
+int plb_allreduce_grads(PlbEngine* e, void* stream);
+
+/* Bit-exact application of the reference's word-level masking (dataloader.py:59-137) on the device. The HOST draws the
+ * reference's random streams in the reference's order (plbert_amd/data.py: MaskedPhonemeDataset.decisions) and hands
+ * over, per sample, the UNCROPPED phoneme ids with a separator after each word, the word boundaries and one decision
+ * per word; the device writes labels / masked ids (cropped to max_seq_length at crop_start, zero padded to S — the
+ * collater's pad, dataloader.py:276-297) and the masked index list re-based to the crop (CSR), exactly as
+ * __getitem__ + the collater produce them. Integer work only: results are bit-identical to the reference's.
+ *   ids int64 [n_total]: all samples' uncropped ids back to back; sample_off int32 [B+1]: offsets into ids;
+ *   word_off int32 [B+1]: offsets into word_begin / word_len / action / word_token (one entry per word: first position
+ *   inside the sample, phoneme count, action 0 keep | 1 mask | 2 replace, grapheme-token id);
+ *   repl int64 [n_total]: replacement ids (read at the positions of action-2 words); crop_start int32 [B];
+ *   word_token + tokens (both NULL, or both given): the 4-tuple Collater's token_ids row, every phoneme of a word
+ *   carrying the word's token id and separators sep_token (dataloader.py:66-71).
+ * Outputs: labels / masked / tokens int64 [B,S]; lengths_out int32 [B] = min(len, S); idx_offsets int32 [B+1];
+ * idx_flat int32 [capacity B*S]; scratch int32 [B + B*S]. S <= 1024, B <= 1024. */
+int plb_apply_mask(const int64_t* ids, const int32_t* sample_off, const int32_t* word_off, const int32_t* word_begin,
+                   const int32_t* word_len, const int8_t* action, const int64_t* repl, const int64_t* word_token,
+                   int64_t sep_token, const int32_t* crop_start, int32_t B, int32_t S, int32_t mask_id, int64_t* labels,
+                   int64_t* masked, int64_t* tokens, int32_t* lengths_out, int32_t* idx_offsets, int32_t* idx_flat,
+                   int32_t* scratch, void* stream);
 
 /* Device-side fast mode of the word-level masking that MaskedPhonemeDataset does on the host
  * (dataloader.py:83-108): same decision tree and probabilities (select a word with word_pred_prob;

@@ -4,7 +4,7 @@ from .config import AlbertConfig, albert_config_from_yaml, load_config
 from .symbols import CharacterIndexer, symbols, PAD_ID, MASK_ID, SEPARATOR_ID, UNKNOWN_ID
 from .init import param_shapes, deterministic_state_dict, reference_init_state_dict
 from .data import (MaskedPhonemeDataset, PhonemeOnlyCollater, Collater, build_dataloader,
-                   length_to_mask, masked_indices_to_csr, synthetic_batch, seed_reference_streams)
+                   length_to_mask, masked_indices_to_csr, synthetic_batch, seed_reference_streams, collate_decisions)
 
 
 
@@ -15,7 +15,7 @@ def __getattr__(name):
         from . import model
         return getattr(model, name)
     if name in ("PLBertTrainer", "process_batch", "AdamW", "StagedBatch", "stage_reference_batch", "validate_batch",
-                "device_mask_batch"):
+                "device_mask_batch", "device_apply_mask"):
         from . import train
         return getattr(train, name)
     if name in ("save_checkpoint", "load_checkpoint", "find_latest_checkpoint"):
@@ -29,10 +29,10 @@ def __getattr__(name):
 
 __all__ = [
     "AlbertModel", "PhonemeOnlyModel", "MultiTaskModel", "PLBertTrainer", "process_batch", "AdamW", "HipEngine",
-    "save_checkpoint", "load_checkpoint", "find_latest_checkpoint", "device_mask_batch",
+    "save_checkpoint", "load_checkpoint", "find_latest_checkpoint", "device_mask_batch", "device_apply_mask",
     "AlbertConfig", "albert_config_from_yaml", "load_config",
     "CharacterIndexer", "symbols", "PAD_ID", "MASK_ID", "SEPARATOR_ID", "UNKNOWN_ID",
     "param_shapes", "deterministic_state_dict", "reference_init_state_dict",
     "MaskedPhonemeDataset", "PhonemeOnlyCollater", "Collater", "build_dataloader",
-    "length_to_mask", "masked_indices_to_csr", "synthetic_batch", "seed_reference_streams",
+    "length_to_mask", "masked_indices_to_csr", "synthetic_batch", "seed_reference_streams", "collate_decisions",
 ]

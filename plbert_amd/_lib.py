@@ -52,8 +52,10 @@ PLB_NPARAM = len(PLB_PARAM_NAMES)
 # every symbol include/plbert.h declares (tests check the library exports all of them)
 PUBLIC_SYMBOLS = [
     "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
-    "plb_sync_weights", "plb_forward", "plb_loss_fwd_bwd", "plb_loss_fwd_bwd_dual", "plb_adamw_step", "plb_mask_batch",
-    "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
+    "plb_sync_weights", "plb_forward", "plb_pooler", "plb_loss_fwd_bwd", "plb_loss_fwd", "plb_loss_fwd_bwd_dual", "plb_adamw_step",
+    "plb_token_head_steps", "plb_set_token_head_steps", "plb_comm_unique_id", "plb_comm_init", "plb_comm_destroy",
+    "plb_comm_info", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
+    "plb_mask_batch", "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
 ]
 
 
@@ -63,6 +65,7 @@ class PlbConfig(C.Structure):
         ("num_attention_heads", C.c_int32), ("intermediate_size", C.c_int32), ("num_hidden_layers", C.c_int32),
         ("max_position_embeddings", C.c_int32), ("type_vocab_size", C.c_int32), ("layer_norm_eps", C.c_float),
         ("num_phonemes", C.c_int32), ("num_tokens", C.c_int32), ("max_batch", C.c_int32), ("max_seq", C.c_int32),
+        ("inference_only", C.c_int32),
     ]
 
 
@@ -93,6 +96,15 @@ class PlbAttn(C.Structure):
         ("B", C.c_int), ("S", C.c_int), ("NH", C.c_int), ("H", C.c_int), ("scale", C.c_float),
         ("ctx", C.c_void_p), ("ldctx", C.c_int), ("lse", C.c_void_p),
         ("dctx", C.c_void_p), ("lddctx", C.c_int), ("delta", C.c_void_p), ("dqkv", C.c_void_p), ("lddqkv", C.c_int),
+    ]
+
+
+class PlbEmbed(C.Structure):
+    _fields_ = [
+        ("ids", C.c_void_p), ("T", C.c_int), ("S", C.c_int), ("E", C.c_int), ("V", C.c_int),
+        ("word", C.c_void_p), ("pos", C.c_void_p), ("type0", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("eps", C.c_float), ("out", C.c_void_p), ("ldo", C.c_int), ("dout", C.c_void_p), ("lddo", C.c_int),
+        ("dx", C.c_void_p), ("dword", C.c_void_p), ("dpos", C.c_void_p), ("partials", C.c_void_p), ("nblocks", C.c_int),
     ]
 
 
@@ -147,6 +159,30 @@ def lib():
     L.plb_loss_fwd_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     L.plb_loss_fwd_bwd_dual.restype = C.c_int
     L.plb_loss_fwd_bwd_dual.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.plb_pooler.restype = C.c_int
+    L.plb_pooler.argtypes = [vp, vp, i32, i32, vp, vp]
+    L.plb_loss_fwd.restype = C.c_int
+    L.plb_loss_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.plb_token_head_steps.restype = i32
+    L.plb_token_head_steps.argtypes = [vp]
+    L.plb_set_token_head_steps.restype = C.c_int
+    L.plb_set_token_head_steps.argtypes = [vp, i32]
+    L.plb_comm_unique_id.restype = C.c_int
+    L.plb_comm_unique_id.argtypes = [vp]
+    L.plb_comm_init.restype = C.c_int
+    L.plb_comm_init.argtypes = [vp, vp, i32, i32]
+    L.plb_comm_destroy.restype = C.c_int
+    L.plb_comm_destroy.argtypes = [vp]
+    L.plb_comm_info.restype = C.c_int
+    L.plb_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.plb_broadcast_params.restype = C.c_int
+    L.plb_broadcast_params.argtypes = [vp, i32, vp]
+    L.plb_set_grad_overlap.restype = C.c_int
+    L.plb_set_grad_overlap.argtypes = [vp, i32]
+    L.plb_allreduce_grads.restype = C.c_int
+    L.plb_allreduce_grads.argtypes = [vp, vp]
+    L.plb_apply_mask.restype = C.c_int
+    L.plb_apply_mask.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.plb_adamw_step.restype = C.c_int
     L.plb_adamw_step.argtypes = [vp, f32, f32, f32, f32, f32, i32, f32, vp]
     L.plb_mask_batch.restype = C.c_int
@@ -180,6 +216,8 @@ def lib():
     L.plb_launch_ln_fwd.argtypes = [C.POINTER(PlbLayerNorm), vp]
     L.plb_launch_ln_bwd.restype = C.c_int
     L.plb_launch_ln_bwd.argtypes = [C.POINTER(PlbLayerNorm), vp]
+    L.plb_launch_embed_scatter.restype = C.c_int
+    L.plb_launch_embed_scatter.argtypes = [C.POINTER(PlbEmbed), C.c_int, vp]
     L.plb_launch_colsum.restype = C.c_int
     L.plb_launch_colsum.argtypes = [vp, C.c_int, C.c_size_t, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, vp]
     _lib = L

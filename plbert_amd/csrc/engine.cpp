@@ -8,10 +8,12 @@
 // that feeds a weight gradient.  Weight sharing then turns the 12 per-layer dW products of the
 // reference's autograd into ONE token-major GEMM per weight with reduction length L*Tp, which is
 // split over the grid into fp32 slabs and reduced in fixed order (deterministic, no atomics).
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <new>
@@ -77,6 +79,52 @@ extern "C" int plb_profile_read(double* ms, int64_t* launches, double* flops, do
   return 0;
 }
 
+// ---- RCCL, resolved at run time -----------------------------------------------------------------------------
+// The library is not linked against RCCL: a Python host has torch's own librccl.so.1 mapped already (one RCCL per
+// process), a C / C++ host gets the system one. Only the handful of entry points of the gradient exchange are bound;
+// types restated from rccl.h (the NCCL API): opaque communicator, 128-byte unique id, int result / enum codes.
+namespace {
+struct RcclId { char internal[128]; };
+typedef void* RcclComm;
+enum { kNcclSuccess = 0, kNcclFloat32 = 7, kNcclSum = 0 };
+struct RcclApi {
+  void* handle = nullptr;
+  int (*GetUniqueId)(RcclId*) = nullptr;
+  int (*CommInitRank)(RcclComm*, int, RcclId, int) = nullptr;
+  int (*CommDestroy)(RcclComm) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, RcclComm, hipStream_t) = nullptr;
+  int (*GetVersion)(int*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+RcclApi g_rccl;
+const char* rccl_load() {  // nullptr on success, else what failed
+  if (g_rccl.ok) return nullptr;
+  const char* env = getenv("PLBERT_RCCL_LIB");
+  void* h = nullptr;
+  if (env && *env) h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // already in the process (torch's copy)
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+  if (!h) return "cannot load librccl.so.1 (set PLBERT_RCCL_LIB)";
+  g_rccl.handle = h;
+#define RSYM(field, name) \
+  *(void**)(&g_rccl.field) = dlsym(h, name); \
+  if (!g_rccl.field) return "librccl lacks " name
+  RSYM(GetUniqueId, "ncclGetUniqueId");
+  RSYM(CommInitRank, "ncclCommInitRank");
+  RSYM(CommDestroy, "ncclCommDestroy");
+  RSYM(AllReduce, "ncclAllReduce");
+  RSYM(Broadcast, "ncclBroadcast");
+  RSYM(GetVersion, "ncclGetVersion");
+  RSYM(GetErrorString, "ncclGetErrorString");
+#undef RSYM
+  g_rccl.ok = true;
+  return nullptr;
+}
+}  // namespace
+
 namespace {
 
 inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
@@ -120,6 +168,16 @@ struct PlbEngine {
   int64_t slab_floats;
   int64_t ws_bytes;
   int ln_blocks, emb_blocks;
+  bool infer = false;           // inference-only workspace: one layer of activations, no gradient stash
+  int tok_steps = 0;            // AdamW steps the token head has taken (its own bias correction)
+  // data-parallel exchange (plb_comm_*): RCCL communicator, its stream, and the join event of the pieces in flight
+  RcclComm comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_piece = nullptr, ev_comm_done = nullptr;
+  bool overlap = true;          // issue the all-reduce piecewise inside plb_loss_fwd_bwd
+  bool comm_pending = false;    // pieces were issued: plb_allreduce_grads / plb_adamw_step must join ev_comm_done
+  bool grads_reduced = false;   // the gradients of the last loss call have been all-reduced
   // bound buffers
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
   char* ws = nullptr;
@@ -201,6 +259,9 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   const int64_t E = e->E, H = e->H, I = e->I, L = e->L;
   const int64_t T = (int64_t)c.max_batch * c.max_seq;
   const int64_t Tp = rup(T, 128);
+  e->infer = c.inference_only != 0;
+  const bool tr = !e->infer;
+  const int64_t Ls = tr ? L : 1;  // layers of activations kept
   e->Tcap = Tp;
   e->NMcap = Tp;
   e->ln_blocks = 1024;
@@ -208,86 +269,96 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   Carve cv;
   // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes
   e->o_wbf = cv.take((e->ptotal + 256 * (H > I ? H : I)) * 2);
-  e->o_wqkvT = cv.take(rup(H, 128) * 3 * H * 2);
-  e->o_wdT = cv.take(rup(H, 128) * H * 2);
-  e->o_w1T = cv.take(rup(H, 128) * I * 2);
-  e->o_w2T = cv.take(rup(I, 128) * H * 2);
-  e->o_wpT = cv.take(rup(H, 128) * 256 * 2);
-  e->o_winT = cv.take(rup(E, 128) * H * 2);
-  // forward stash
+  if (tr) {
+    e->o_wqkvT = cv.take(rup(H, 128) * 3 * H * 2);
+    e->o_wdT = cv.take(rup(H, 128) * H * 2);
+    e->o_w1T = cv.take(rup(H, 128) * I * 2);
+    e->o_w2T = cv.take(rup(I, 128) * H * 2);
+    e->o_wpT = cv.take(rup(H, 128) * 256 * 2);
+    e->o_winT = cv.take(rup(E, 128) * H * 2);
+  }
+  // forward stash (training: every layer; inference: one layer, two ping-pong slots of x)
   e->o_e = cv.take(Tp * E * 2);
-  e->o_x = cv.take((L + 1) * Tp * H * 2);
-  e->o_qkv = cv.take(L * Tp * 3 * H * 2);
-  e->o_ctx = cv.take(L * Tp * H * 2);
-  e->o_pre1 = cv.take(L * Tp * H * 2);
-  e->o_a = cv.take(L * Tp * H * 2);
-  e->o_u = cv.take(L * Tp * I * 2);
-  e->o_g = cv.take(L * Tp * I * 2);
-  e->o_pre2 = cv.take(L * Tp * H * 2);
+  e->o_x = cv.take((tr ? L + 1 : 2) * Tp * H * 2);
+  e->o_qkv = cv.take(Ls * Tp * 3 * H * 2);
+  e->o_ctx = cv.take(Ls * Tp * H * 2);
+  e->o_pre1 = cv.take(Ls * Tp * H * 2);
+  e->o_a = cv.take(Ls * Tp * H * 2);
+  e->o_u = cv.take(Ls * Tp * I * 2);
+  e->o_g = cv.take(Ls * Tp * I * 2);
+  e->o_pre2 = cv.take(Ls * Tp * H * 2);
   const int64_t stat = (int64_t)c.max_batch * e->NH * c.max_seq * 4;
-  e->o_lse = cv.take(L * stat);
-  e->o_delta = cv.take(stat);
-  e->o_mean1 = cv.take(L * Tp * 4); e->o_rstd1 = cv.take(L * Tp * 4);
-  e->o_mean2 = cv.take(L * Tp * 4); e->o_rstd2 = cv.take(L * Tp * 4);
-  // backward stash (operands of the batched dW GEMMs)
-  e->o_dqkv = cv.take(L * Tp * 3 * H * 2);
-  e->o_dpre1 = cv.take(L * Tp * H * 2);
-  e->o_du = cv.take(L * Tp * I * 2);
-  e->o_dpre2 = cv.take(L * Tp * H * 2);
-  e->o_dy0 = cv.take(Tp * H * 2); e->o_dy1 = cv.take(Tp * H * 2);
-  e->o_da = cv.take(Tp * H * 2); e->o_dctx = cv.take(Tp * H * 2);
-  e->o_de = cv.take(Tp * E * 2);
+  e->o_lse = cv.take(Ls * stat);
+  e->o_mean1 = cv.take(Ls * Tp * 4); e->o_rstd1 = cv.take(Ls * Tp * 4);
+  e->o_mean2 = cv.take(Ls * Tp * 4); e->o_rstd2 = cv.take(Ls * Tp * 4);
+  if (tr) {
+    e->o_delta = cv.take(stat);
+    // backward stash (operands of the batched dW GEMMs)
+    e->o_dqkv = cv.take(L * Tp * 3 * H * 2);
+    e->o_dpre1 = cv.take(L * Tp * H * 2);
+    e->o_du = cv.take(L * Tp * I * 2);
+    e->o_dpre2 = cv.take(L * Tp * H * 2);
+    e->o_dy0 = cv.take(Tp * H * 2); e->o_dy1 = cv.take(Tp * H * 2);
+    e->o_da = cv.take(Tp * H * 2); e->o_dctx = cv.take(Tp * H * 2);
+    e->o_de = cv.take(Tp * E * 2);
+  }
   // loss rows
   const int64_t NM = e->NMcap;
   e->o_hm = cv.take(NM * H * 2);
   e->o_logm = cv.take(NM * 256 * 4);
   e->o_dlog = cv.take(NM * 256 * 2);
-  e->o_dhm = cv.take(NM * H * 2);
   e->o_rows = cv.take(NM * 4); e->o_tgt = cv.take(NM * 4); e->o_w = cv.take(NM * 4); e->o_lrows = cv.take(NM * 4);
-  // reductions
-  int64_t slab = 0;
-  {
-    const int64_t Mtot = L * Tp;
-    const int ntp = (int)rup(e->NT, 256);
-    const int shapes[7][2] = {{(int)(3 * H), (int)H}, {(int)H, (int)H}, {(int)I, (int)H}, {(int)H, (int)I}, {(int)H, (int)E}, {e->NP, (int)H}, {ntp, (int)H}};
-    for (int i = 0; i < (e->NT ? 7 : 6); ++i) {
-      int rps;
-      const int64_t mt = i < 4 ? Mtot : Tp;
-      const int s = tn_splits(mt, shapes[i][0], shapes[i][1], &rps);
-      const int64_t f = (int64_t)s * shapes[i][0] * shapes[i][1];
-      if (f > slab) slab = f;
+  if (tr) {
+    e->o_dhm = cv.take(NM * H * 2);
+    // reductions
+    int64_t slab = 0;
+    {
+      const int64_t Mtot = L * Tp;
+      const int ntp = (int)rup(e->NT, 256);
+      const int shapes[7][2] = {{(int)(3 * H), (int)H}, {(int)H, (int)H}, {(int)I, (int)H}, {(int)H, (int)I}, {(int)H, (int)E}, {e->NP, (int)H}, {ntp, (int)H}};
+      for (int i = 0; i < (e->NT ? 7 : 6); ++i) {
+        int rps;
+        const int64_t mt = i < 4 ? Mtot : Tp;
+        const int s = tn_splits(mt, shapes[i][0], shapes[i][1], &rps);
+        const int64_t f = (int64_t)s * shapes[i][0] * shapes[i][1];
+        if (f > slab) slab = f;
+      }
     }
-  }
-  e->slab_floats = slab;
-  e->o_slab = cv.take(slab * 4);
-  e->o_part1 = cv.take(L * e->ln_blocks * 2 * H * 4);  // per LN-backward block: dgamma | dbeta
-  e->o_part2 = cv.take(L * e->ln_blocks * 2 * H * 4);
-  e->o_parte = cv.take((int64_t)e->emb_blocks * 2 * E * 4);
-  e->o_dxe = cv.take(Tp * E * 4);
-  e->o_ducol = cv.take(L * (2 * Tp / 128) * I * 4);  // column-sum partials of dU from the GEMM epilogue
-  e->o_scratch = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);  // colsum partials: up to 512 row splits
-  e->o_scratch2 = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);
-  {
-    int rps;
-    const int s2 = tn_splits(Tp, (int)H, (int)E, &rps);
-    e->slab2_floats = (int64_t)s2 * H * E;
-    e->o_slab2 = cv.take(e->slab2_floats * 4);
+    e->slab_floats = slab;
+    e->o_slab = cv.take(slab * 4);
+    e->o_part1 = cv.take(L * e->ln_blocks * 3 * H * 4);  // per LN-backward block: dgamma | dbeta | column sums of dx
+    e->o_part2 = cv.take(L * e->ln_blocks * 3 * H * 4);
+    e->o_parte = cv.take((int64_t)e->emb_blocks * 2 * E * 4);
+    e->o_dxe = cv.take(Tp * E * 4);
+    e->o_ducol = cv.take(L * (2 * Tp / 128) * I * 4);  // column-sum partials of dU from the GEMM epilogue
+    e->o_scratch = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);  // colsum partials: up to 512 row splits
+    e->o_scratch2 = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);
+    {
+      int rps;
+      const int s2 = tn_splits(Tp, (int)H, (int)E, &rps);
+      e->slab2_floats = (int64_t)s2 * H * E;
+      e->o_slab2 = cv.take(e->slab2_floats * 4);
+    }
   }
   if (e->NT) {
     const int64_t NTp = rup(e->NT, 256);
     e->NTp = (int)NTp;
     e->o_bt = cv.take(NTp * 4);
-    e->o_wtT = cv.take(rup(H, 128) * NTp * 2);
-    e->o_tdl = cv.take(Tp * NTp * 2);
     e->o_tlrows = cv.take(Tp * 4);
-    e->o_tscr = cv.take(32 * NTp * 4);
     e->o_tpmax = cv.take(Tp * (NTp / 256) * 4);
     e->o_tpsum = cv.take(Tp * (NTp / 256) * 4);
     e->o_ttl = cv.take(Tp * 4); e->o_tlse = cv.take(Tp * 4); e->o_tw = cv.take(Tp * 4);
     e->o_ttgt = cv.take(Tp * 8);
-    e->o_tcolp = cv.take(2 * (Tp / 128) * NTp * 4);
-    e->o_tgrad = cv.take(NTp * H * 4);
     e->o_tloss = cv.take(256);
+    // zero-padded [NTp,H] bf16 copy of the token head for the fused GEMM + CE passes (the flat copy's rows past NT
+    // belong to the next tensor)
+    if (tr) {
+      e->o_wtT = cv.take(rup(H, 128) * NTp * 2);
+      e->o_tdl = cv.take(Tp * NTp * 2);
+      e->o_tscr = cv.take(32 * NTp * 4);
+      e->o_tcolp = cv.take(2 * (Tp / 128) * NTp * 4);
+      e->o_tgrad = cv.take(NTp * H * 4);
+    }
   }
   e->ws_bytes = cv.off;
   *out = e;
@@ -296,6 +367,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
 
 extern "C" void plb_destroy(PlbEngine* e) {
   if (!e) return;
+  (void)plb_comm_destroy(e);
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->side) (void)hipStreamDestroy(e->side);
@@ -347,6 +419,11 @@ extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_av
 
 static int sync_transposes(PlbEngine* e, hipStream_t s) {
   const int H = e->H, I = e->I, E = e->E;
+  if (e->NT) {  // bias of the token head padded to NTp columns (fused GEMM + CE passes)
+    if (!e->tok_pad_zeroed) HIPTRY(hipMemsetAsync(e->at<float>(e->o_bt), 0, (size_t)e->NTp * 4, s));
+    HIPTRY(hipMemcpyAsync(e->at<float>(e->o_bt), e->par(PLB_TOK_B), (size_t)e->NT * 4, hipMemcpyDeviceToDevice, s));
+  }
+  if (e->infer) { e->tok_pad_zeroed = true; return 0; }  // the transposed copies serve the backward only
   // fused QKV [3H,H] -> [H,3H]; the three tensors are adjacent in the flat buffer
   TRY(plb_launch_transpose_cast(e->par(PLB_Q_W), 3 * H, H, e->at<bf16_t>(e->o_wqkvT), 3 * H, s));
   TRY(plb_launch_transpose_cast(e->par(PLB_DENSE_W), H, H, e->at<bf16_t>(e->o_wdT), H, s));
@@ -354,15 +431,11 @@ static int sync_transposes(PlbEngine* e, hipStream_t s) {
   TRY(plb_launch_transpose_cast(e->par(PLB_FFNO_W), H, I, e->at<bf16_t>(e->o_w2T), H, s));
   TRY(plb_launch_transpose_cast(e->par(PLB_HEAD_W), e->NP, H, e->at<bf16_t>(e->o_wpT), 256, s));
   TRY(plb_launch_transpose_cast(e->par(PLB_MAP_W), H, E, e->at<bf16_t>(e->o_winT), H, s));
-  if (e->NT && e->grads) {  // training copies of the token head: transposed weight and bias, padded to NTp columns
-    if (!e->tok_pad_zeroed) {
-      HIPTRY(hipMemsetAsync(e->at<bf16_t>(e->o_wtT), 0, (size_t)rup(H, 128) * e->NTp * 2, s));
-      HIPTRY(hipMemsetAsync(e->at<float>(e->o_bt), 0, (size_t)e->NTp * 4, s));
-      e->tok_pad_zeroed = true;
-    }
+  if (e->NT) {  // transposed weight of the token head, padded to NTp columns
+    if (!e->tok_pad_zeroed) HIPTRY(hipMemsetAsync(e->at<bf16_t>(e->o_wtT), 0, (size_t)rup(H, 128) * e->NTp * 2, s));
     TRY(plb_launch_transpose_cast(e->par(PLB_TOK_W), e->NT, H, e->at<bf16_t>(e->o_wtT), e->NTp, s));
-    HIPTRY(hipMemcpyAsync(e->at<float>(e->o_bt), e->par(PLB_TOK_B), (size_t)e->NT * 4, hipMemcpyDeviceToDevice, s));
   }
+  e->tok_pad_zeroed = true;
   return 0;
 }
 
@@ -481,6 +554,13 @@ extern "C" int plb_forward(PlbEngine* e, const int64_t* ids, const int32_t* leng
   return 0;
 }
 
+extern "C" int plb_pooler(PlbEngine* e, const float* hidden, int32_t B, int32_t S, float* pooled, void* stream) {
+  if (!e || !e->ws) return fail("plb_pooler: engine not bound");
+  if (!hidden || !pooled || B < 1 || S < 1) return fail("plb_pooler: bad argument");
+  TRY(plb_launch_pooler(hidden, B, S, e->H, e->par(PLB_POOL_W), e->par(PLB_POOL_B), pooled, (hipStream_t)stream));
+  return 0;
+}
+
 // dW[N,K] = A^T B over Mtot rows -> grads[which] (overwrite)
 static int weight_grad(PlbEngine* e, const bf16_t* A, int lda, int Ncols, const bf16_t* Bm, int ldb, int64_t Mtot, int N,
                        int K, float* out, hipStream_t s, bool side_slab = false) {
@@ -502,27 +582,63 @@ static int weight_grad(PlbEngine* e, const bf16_t* A, int lda, int Ncols, const 
   return 0;
 }
 
+static int backward_tail(PlbEngine* e, const int64_t* masked_ids, bf16_t* dy, int B, int S, int du_rows, hipStream_t s);
+
+// ---- gradient exchange pieces ---------------------------------------------------------------------------------
+// One sum all-reduce of grads[a, b) on the communication stream, ordered after everything enqueued on `after` so far.
+static int reduce_piece(PlbEngine* e, int64_t a, int64_t b, hipStream_t after) {
+  if (!e->comm || b <= a) return 0;
+  HIPTRY(hipEventRecord(e->ev_piece, after));
+  HIPTRY(hipStreamWaitEvent(e->comm_stream, e->ev_piece, 0));
+  const int rc = g_rccl.AllReduce(e->grads + a, e->grads + a, (size_t)(b - a), kNcclFloat32, kNcclSum, e->comm, e->comm_stream);
+  if (rc != kNcclSuccess) return fail("ncclAllReduce: %s", g_rccl.GetErrorString(rc));
+  e->comm_pending = true;
+  return 0;
+}
+static bool overlapping(const PlbEngine* e) { return e->comm && e->overlap; }
+// Close the pieces issued so far: later joins wait on ev_comm_done.
+static int pieces_done(PlbEngine* e) {
+  if (!e->comm_pending) return 0;
+  HIPTRY(hipEventRecord(e->ev_comm_done, e->comm_stream));
+  e->grads_reduced = true;
+  return 0;
+}
+
 // token_targets == NULL: the reference's phoneme-only step. Otherwise dual-head: loss = phoneme loss + token loss.
-static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int64_t* token_targets,
-                             const int32_t* lengths, const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked,
-                             int32_t B, int32_t S, float* loss, float* loss_parts, void* stream) {
-  if (check_shape(e, B, S, "plb_loss_fwd_bwd")) return 1;
-  if (!e->grads) return fail("plb_loss_fwd_bwd: no gradient buffer bound");
-  if (!masked_ids || !labels || !idx_offsets || !loss) return fail("plb_loss_fwd_bwd: null argument");
-  if (n_masked < 0 || n_masked > e->NMcap) return fail("plb_loss_fwd_bwd: n_masked %d out of range", n_masked);
-  if (token_targets && !e->NT) return fail("plb_loss_fwd_bwd_dual: the engine has no token head (num_tokens = 0)");
+// backward == false: validate() — forward and loss only, one layer of activations, the gradient buffer untouched.
+static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, const int64_t* labels,
+                     const int64_t* token_targets, const int32_t* lengths, const int32_t* idx_offsets,
+                     const int32_t* idx_flat, int32_t n_masked, int32_t B, int32_t S, float* loss, float* loss_parts,
+                     void* stream) {
+  const char* who = backward ? "plb_loss_fwd_bwd" : "plb_loss_fwd";
+  if (check_shape(e, B, S, who)) return 1;
+  if (backward && e->infer) return fail("%s: inference-only engine (PlbConfig.inference_only = 1)", who);
+  if (backward && !e->grads) return fail("%s: no gradient buffer bound", who);
+  if (!masked_ids || !labels || !idx_offsets || !loss) return fail("%s: null argument", who);
+  if (n_masked < 0 || n_masked > e->NMcap) return fail("%s: n_masked %d out of range", who, n_masked);
+  if (token_targets && !e->NT) return fail("%s: the engine has no token head (num_tokens = 0)", who);
   hipStream_t s = (hipStream_t)stream;
-  const int E = e->E, H = e->H, I = e->I, L = e->L, NP = e->NP;
+  const int H = e->H, I = e->I, L = e->L, NP = e->NP;
   const int T = B * S;
   const int64_t Tp = rup(T, 128);
-  e->tok_grads_live = token_targets != nullptr;
+  if (backward) {
+    e->tok_grads_live = token_targets != nullptr;
+    e->comm_pending = false;
+    e->grads_reduced = false;
+  }
   if (n_masked == 0 && !token_targets) {  // train.py:129 — zero loss, nothing to back-propagate
     HIPTRY(hipMemsetAsync(loss, 0, sizeof(float), s));
-    HIPTRY(hipMemsetAsync(e->grads, 0, (size_t)e->ptrain * 4, s));
+    if (backward) {
+      HIPTRY(hipMemsetAsync(e->grads, 0, (size_t)e->ptrain * 4, s));
+      if (overlapping(e)) {  // the other ranks still contribute theirs
+        if (reduce_piece(e, 0, e->ptrain, s)) return 1;
+        if (pieces_done(e)) return 1;
+      }
+    }
     return 0;
   }
   bf16_t* xL = nullptr;
-  if (run_encoder(e, masked_ids, lengths, B, S, true, &xL, s)) return 1;
+  if (run_encoder(e, masked_ids, lengths, B, S, backward, &xL, s)) return 1;
 
   // ---- masked rows: head GEMM, cross-entropy, head gradients ----------------------------------------
   const int NM = (int)rup(n_masked, 128);
@@ -533,12 +649,12 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
   bf16_t* hm = e->at<bf16_t>(e->o_hm);
   float* logm = e->at<float>(e->o_logm);
   bf16_t* dlog = e->at<bf16_t>(e->o_dlog);
-  bf16_t* dhm = e->at<bf16_t>(e->o_dhm);
-  float* scratch = e->at<float>(e->o_scratch);
-  bf16_t* dy = e->at<bf16_t>(e->o_dy0);
-  bf16_t* dy_other = e->at<bf16_t>(e->o_dy1);
+  bf16_t* dhm = backward ? e->at<bf16_t>(e->o_dhm) : nullptr;
+  float* scratch = backward ? e->at<float>(e->o_scratch) : nullptr;
+  bf16_t* dy = backward ? e->at<bf16_t>(e->o_dy0) : nullptr;
+  bf16_t* dy_other = backward ? e->at<bf16_t>(e->o_dy1) : nullptr;
   PlbGemmNT g;
-  HIPTRY(hipMemsetAsync(dy, 0, (size_t)Tp * H * 2, s));
+  if (backward) HIPTRY(hipMemsetAsync(dy, 0, (size_t)Tp * H * 2, s));
   if (n_masked > 0) {
     TRY(plb_launch_ce_prepare(idx_offsets, idx_flat, labels, B, S, rows, tgt, w, s));
     TRY(plb_launch_gather_rows(xL, H, rows, n_masked, NM, H, hm, H, s));
@@ -548,17 +664,22 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
     TRY(plb_launch_gemm_nt(&g, 0, 1, s));
     TRY(plb_launch_ce_fwd_bwd(logm, 256, NP, tgt, w, n_masked, NM, lrows, dlog, 256, s));
     TRY(plb_launch_sum_rows(lrows, n_masked, loss, s));
-    if (weight_grad(e, dlog, 256, 256, hm, H, NM, NP, H, e->grd(PLB_HEAD_W), s)) return 1;
-    TRY(plb_launch_colsum(dlog, 1, (size_t)NM, 256, 256, e->grd(PLB_HEAD_B), NP, 0, scratch, 8, s));
-    memset(&g, 0, sizeof(g));
-    g.A = dlog; g.lda = 256; g.B = e->at<bf16_t>(e->o_wpT); g.ldb = 256; g.M = NM; g.N = H; g.K = 256; g.Mstore = NM;
-    g.C = dhm; g.ldc = H;
-    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
-    TRY(plb_launch_scatter_rows(dhm, H, rows, n_masked, H, dy, H, s));
+    if (backward) {
+      if (weight_grad(e, dlog, 256, 256, hm, H, NM, NP, H, e->grd(PLB_HEAD_W), s)) return 1;
+      TRY(plb_launch_colsum(dlog, 1, (size_t)NM, 256, 256, e->grd(PLB_HEAD_B), NP, 0, scratch, 8, s));
+      memset(&g, 0, sizeof(g));
+      g.A = dlog; g.lda = 256; g.B = e->at<bf16_t>(e->o_wpT); g.ldb = 256; g.M = NM; g.N = H; g.K = 256; g.Mstore = NM;
+      g.C = dhm; g.ldc = H;
+      TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+      TRY(plb_launch_scatter_rows(dhm, H, rows, n_masked, H, dy, H, s));
+    }
   } else {  // dual-head step on a batch without masked phonemes: phoneme loss 0, its head gets zero gradients
     HIPTRY(hipMemsetAsync(loss, 0, sizeof(float), s));
-    HIPTRY(hipMemsetAsync(e->grd(PLB_HEAD_W), 0, (size_t)(e->psize[PLB_HEAD_W] + e->psize[PLB_HEAD_B]) * 4, s));
+    if (backward)
+      HIPTRY(hipMemsetAsync(e->grd(PLB_HEAD_W), 0, (size_t)(e->psize[PLB_HEAD_W] + e->psize[PLB_HEAD_B]) * 4, s));
   }
+  // the phoneme head's gradients are final: their all-reduce runs beside the whole backward
+  if (backward && overlapping(e) && reduce_piece(e, e->poff[PLB_HEAD_W], e->ptrain, s)) return 1;
   if (loss_parts) HIPTRY(hipMemcpyAsync(loss_parts, loss, sizeof(float), hipMemcpyDeviceToDevice, s));
 
   // ---- token (grapheme) head over every valid position: fused GEMM + cross-entropy, head gradients, dH ------------
@@ -571,7 +692,6 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
     const int NT = e->NT, NTp = e->NTp;
     const int tile = (Tp % 256 == 0) ? 256 : 1256;          // 256x256 or 128x256: both 256 columns wide
     const int ntile = NTp / 256, cprows = tile == 256 ? 2 * (int)(Tp / 256) : 2 * (int)(Tp / 128);
-    bf16_t* tdl = e->at<bf16_t>(e->o_tdl);
     float* tlrows = e->at<float>(e->o_tlrows);
     float* tloss = e->at<float>(e->o_tloss);
     int64_t* ttgt = e->at<int64_t>(e->o_ttgt);
@@ -591,22 +711,27 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
     TRY(plb_launch_sum_rows(tlrows, T, tloss, s));
     TRY(plb_launch_add_scalar(loss, loss, tloss, s));
     if (loss_parts) HIPTRY(hipMemcpyAsync(loss_parts + 1, tloss, sizeof(float), hipMemcpyDeviceToDevice, s));
-    g.ce_lse = e->at<float>(e->o_tlse); g.ce_w = e->at<float>(e->o_tw);
-    g.C = tdl; g.ldc = NTp; g.colpart = e->at<float>(e->o_tcolp);
-    tok = plb_prof_begin(PLB_K_GEMM_NT_CE, s, ce_flops, 0.0);
-    TRY(plb_launch_gemm_nt_big(&g, tile, 4, 0, s));
-    plb_prof_end(tok, s);
-    TRY(plb_launch_colsum(g.colpart, 0, (size_t)cprows, NTp, NTp, e->grd(PLB_TOK_B), NT, 0, e->at<float>(e->o_tscr), 1, s));
-    float* gw = NTp == NT ? e->grd(PLB_TOK_W) : e->at<float>(e->o_tgrad);
-    if (weight_grad(e, tdl, NTp, NTp, xL, H, Tp, NTp, H, gw, s)) return 1;
-    if (NTp != NT) HIPTRY(hipMemcpyAsync(e->grd(PLB_TOK_W), gw, (size_t)NT * H * 4, hipMemcpyDeviceToDevice, s));
-    // dH += dlogits · Wt, on top of the scattered phoneme-head rows (in place: a tile reads its residual
-    // before its own stores)
-    memset(&g, 0, sizeof(g));
-    g.A = tdl; g.lda = NTp; g.B = e->at<bf16_t>(e->o_wtT); g.ldb = NTp; g.M = (int)Tp; g.N = H; g.K = NTp; g.Mstore = (int)Tp;
-    g.res = dy; g.ldr = H; g.C = dy; g.ldc = H;
-    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    if (backward) {
+      bf16_t* tdl = e->at<bf16_t>(e->o_tdl);
+      g.ce_lse = e->at<float>(e->o_tlse); g.ce_w = e->at<float>(e->o_tw);
+      g.C = tdl; g.ldc = NTp; g.colpart = e->at<float>(e->o_tcolp);
+      tok = plb_prof_begin(PLB_K_GEMM_NT_CE, s, ce_flops, 0.0);
+      TRY(plb_launch_gemm_nt_big(&g, tile, 4, 0, s));
+      plb_prof_end(tok, s);
+      TRY(plb_launch_colsum(g.colpart, 0, (size_t)cprows, NTp, NTp, e->grd(PLB_TOK_B), NT, 0, e->at<float>(e->o_tscr), 1, s));
+      float* gw = NTp == NT ? e->grd(PLB_TOK_W) : e->at<float>(e->o_tgrad);
+      if (weight_grad(e, tdl, NTp, NTp, xL, H, Tp, NTp, H, gw, s)) return 1;
+      if (NTp != NT) HIPTRY(hipMemcpyAsync(e->grd(PLB_TOK_W), gw, (size_t)NT * H * 4, hipMemcpyDeviceToDevice, s));
+      if (overlapping(e) && reduce_piece(e, e->poff[PLB_TOK_W], e->ptotal, s)) return 1;
+      // dH += dlogits · Wt, on top of the scattered phoneme-head rows (in place: a tile reads its residual
+      // before its own stores)
+      memset(&g, 0, sizeof(g));
+      g.A = tdl; g.lda = NTp; g.B = e->at<bf16_t>(e->o_wtT); g.ldb = NTp; g.M = (int)Tp; g.N = H; g.K = NTp; g.Mstore = (int)Tp;
+      g.res = dy; g.ldr = H; g.C = dy; g.ldc = H;
+      TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    }
   }
+  if (!backward) return 0;
 
   // ---- layers in reverse --------------------------------------------------------------------------------
   const int du_rows = plb_gemm_nt_colpart_rows((int)Tp, I, H);  // ffn.bias gradient from the dU GEMM's epilogue
@@ -627,7 +752,7 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
     ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
     ln.mean = e->at<float>(e->o_mean2) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd2) + (int64_t)l * Tp;
     ln.dy = dy; ln.lddy = H; ln.dx = dpre2; ln.lddx = H;
-    ln.partials = e->at<float>(e->o_part2) + (int64_t)l * e->ln_blocks * 2 * H; ln.nblocks = e->ln_blocks;
+    ln.partials = e->at<float>(e->o_part2) + (int64_t)l * e->ln_blocks * 3 * H; ln.nblocks = e->ln_blocks;
     TRY(plb_launch_ln_bwd(&ln, s));
     // dU = (dpre2 · W2) ∘ gelu'(u)
     memset(&g, 0, sizeof(g));
@@ -644,7 +769,7 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
     ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
     ln.mean = e->at<float>(e->o_mean1) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd1) + (int64_t)l * Tp;
     ln.dy = da; ln.lddy = H; ln.dx = dpre1; ln.lddx = H;
-    ln.partials = e->at<float>(e->o_part1) + (int64_t)l * e->ln_blocks * 2 * H; ln.nblocks = e->ln_blocks;
+    ln.partials = e->at<float>(e->o_part1) + (int64_t)l * e->ln_blocks * 3 * H; ln.nblocks = e->ln_blocks;
     TRY(plb_launch_ln_bwd(&ln, s));
     // dCtx = dpre1 · Wd
     memset(&g, 0, sizeof(g));
@@ -665,20 +790,24 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
     TRY(plb_launch_gemm_nt(&g, 0, 0, s));
     bf16_t* tmp = dy; dy = dy_other; dy_other = tmp;
   }
+  return backward_tail(e, masked_ids, dy, B, S, du_rows, s);
+}
 
-  // ---- tail of the backward on two streams --------------------------------------------------------------------
-  // main: the four large token-major weight-gradient GEMMs (MFMA-bound, ~2 ms at config A).
-  // side: everything else that only needs finished gradients — embedding chain, bias and LayerNorm-affine
-  //       column sums (HBM-bound, ~0.8 ms) — with its own slab / scratch so nothing is shared.
-  hipStream_t s2 = s;
-  float* scratch2 = scratch;
-  if (e->side) {
-    s2 = e->side;
-    scratch2 = e->at<float>(e->o_scratch2);
-    HIPTRY(hipEventRecord(e->ev_fork, s));
-    HIPTRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
-  }
+// Tail of the backward on two streams.
+//  main: the four large token-major weight-gradient GEMMs (MFMA-bound, ~2 ms at config A), each followed — when a
+//        communicator is attached — by the all-reduce of the contiguous piece of the flat gradient buffer it completed,
+//        on the communication stream: piece i travels over xGMI while GEMM i+1 runs. The smallest GEMM goes last, so
+//        only dense.weight's piece (2.4 MB of 23.4) has nothing left to hide behind.
+//  side: everything else that only needs finished gradients — embedding chain, bias and LayerNorm-affine column sums
+//        (HBM-bound) — with its own slab / scratch so nothing is shared; joined before the first piece that holds
+//        any of its outputs.
+static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t* dy, int B, int S, int du_rows,
+                                 hipStream_t s, hipStream_t s2, float* scratch2) {
+  const int E = e->E, H = e->H, I = e->I, L = e->L;
+  const int T = B * S;
+  const int64_t Tp = rup(T, 128);
   const int64_t Mtot = (int64_t)L * Tp;
+  PlbGemmNT g;
   // side stream -------------------------------------------------------------------------------------------------------
   bf16_t* evec = e->at<bf16_t>(e->o_e);
   bf16_t* de = e->at<bf16_t>(e->o_de);
@@ -686,7 +815,7 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
   g.A = dy; g.lda = H; g.B = e->at<bf16_t>(e->o_winT); g.ldb = H; g.M = (int)Tp; g.N = E; g.K = H; g.Mstore = (int)Tp;
   g.C = de; g.ldc = E;
   TRY(plb_launch_gemm_nt(&g, 0, 0, s2));
-  if (weight_grad(e, dy, H, H, evec, E, Tp, H, E, e->grd(PLB_MAP_W), s2, e->side != nullptr)) return 1;
+  if (weight_grad(e, dy, H, H, evec, E, Tp, H, E, e->grd(PLB_MAP_W), s2, s2 != s)) return 1;
   TRY(plb_launch_colsum(dy, 1, (size_t)Tp, H, H, e->grd(PLB_MAP_B), H, 0, scratch2, 128, s2));
   HIPTRY(hipMemsetAsync(e->grd(PLB_TYPE_EMB), 0, (size_t)e->psize[PLB_TYPE_EMB] * 4, s2));
   PlbEmbed em;
@@ -707,28 +836,56 @@ static int loss_fwd_bwd_impl(PlbEngine* e, const int64_t* masked_ids, const int6
     TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 16, s2));
   else
     TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 64, s2));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre1), 1, (size_t)Mtot, H, H, e->grd(PLB_DENSE_B), H, 0, scratch2, 128, s2));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dpre2), 1, (size_t)Mtot, H, H, e->grd(PLB_FFNO_B), H, 0, scratch2, 128, s2));
-  const size_t prow = (size_t)L * e->ln_blocks;  // LayerNorm-backward partials [L*blocks][2H]: dgamma | dbeta
-  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 2 * H, 2 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch2, 16, s2));
-  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 2 * H, 2 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch2, 16, s2));
+  // LayerNorm-backward partials [L*blocks][3H]: dgamma | dbeta | column sums of dx. The third block is the bias
+  // gradient of the Linear that produced the LayerNorm's input (dense.bias = colsum(dpre1), ffn_output.bias =
+  // colsum(dpre2)): no pass over the stacked gradients.
+  const size_t prow = (size_t)L * e->ln_blocks;
+  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch2, 16, s2));
+  TRY(plb_launch_copy_cols(scratch2, 16, 3 * H, 2 * H, H, e->grd(PLB_DENSE_B), s2));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch2, 16, s2));
+  TRY(plb_launch_copy_cols(scratch2, 16, 3 * H, 2 * H, H, e->grd(PLB_FFNO_B), s2));
+  if (s2 != s) HIPTRY(hipEventRecord(e->ev_join, s2));
   // main stream: shared-layer weight gradients, one token-major GEMM per weight over all L applications ------------
+  const bool ov = overlapping(e);
   if (weight_grad(e, e->at<bf16_t>(e->o_dqkv), 3 * H, 3 * H, e->at<bf16_t>(e->o_x), H, Mtot, 3 * H, H, e->grd(PLB_Q_W), s)) return 1;
-  if (weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
-  if (weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
-  if (weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
-  if (e->side) {
-    HIPTRY(hipEventRecord(e->ev_join, s2));
-    HIPTRY(hipStreamWaitEvent(s, e->ev_join, 0));
+  if (ov) {  // [0, dense.weight): embeddings, map-in, LN2, QKV weights and biases — the side stream's share must be in
+    if (s2 != s) HIPTRY(hipStreamWaitEvent(s, e->ev_join, 0));
+    if (reduce_piece(e, 0, e->poff[PLB_DENSE_W], s)) return 1;
   }
+  if (weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
+  if (ov && reduce_piece(e, e->poff[PLB_FFN_W], e->poff[PLB_FFNO_W], s)) return 1;
+  if (weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
+  if (ov && reduce_piece(e, e->poff[PLB_FFNO_W], e->poff[PLB_HEAD_W], s)) return 1;
+  if (weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
+  if (ov && reduce_piece(e, e->poff[PLB_DENSE_W], e->poff[PLB_FFN_W], s)) return 1;
   return 0;
+}
+
+static int backward_tail(PlbEngine* e, const int64_t* masked_ids, bf16_t* dy, int B, int S, int du_rows, hipStream_t s) {
+  hipStream_t s2 = s;
+  float* scratch2 = e->at<float>(e->o_scratch);
+  if (e->side) {
+    s2 = e->side;
+    scratch2 = e->at<float>(e->o_scratch2);
+    HIPTRY(hipEventRecord(e->ev_fork, s));
+    HIPTRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
+  }
+  const int rc = backward_tail_streams(e, masked_ids, dy, B, S, du_rows, s, s2, scratch2);
+  // Whatever happened above, the caller's stream must not run ahead of the side stream's work (also on an error
+  // path: the side stream may hold launches that read buffers the caller is about to reuse).
+  if (s2 != s) {
+    if (rc) (void)hipEventRecord(e->ev_join, s2);
+    const hipError_t je = hipStreamWaitEvent(s, e->ev_join, 0);
+    if (!rc && je != hipSuccess) return fail("plb_loss_fwd_bwd: joining the side stream: %s", hipGetErrorString(je));
+  }
+  if (rc) return rc;
+  return pieces_done(e);
 }
 
 extern "C" int plb_loss_fwd_bwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int32_t* lengths,
                                 const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked, int32_t B,
                                 int32_t S, float* loss, void* stream) {
-  return loss_fwd_bwd_impl(e, masked_ids, labels, nullptr, lengths, idx_offsets, idx_flat, n_masked, B, S, loss, nullptr,
-                           stream);
+  return loss_impl(e, true, masked_ids, labels, nullptr, lengths, idx_offsets, idx_flat, n_masked, B, S, loss, nullptr, stream);
 }
 
 extern "C" int plb_loss_fwd_bwd_dual(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels,
@@ -736,8 +893,139 @@ extern "C" int plb_loss_fwd_bwd_dual(PlbEngine* e, const int64_t* masked_ids, co
                                      const int32_t* idx_flat, int32_t n_masked, int32_t B, int32_t S, float* loss,
                                      float* loss_parts, void* stream) {
   if (!token_ids) return fail("plb_loss_fwd_bwd_dual: token_ids is null");
-  return loss_fwd_bwd_impl(e, masked_ids, labels, token_ids, lengths, idx_offsets, idx_flat, n_masked, B, S, loss,
-                           loss_parts, stream);
+  return loss_impl(e, true, masked_ids, labels, token_ids, lengths, idx_offsets, idx_flat, n_masked, B, S, loss, loss_parts,
+                   stream);
+}
+
+extern "C" int plb_loss_fwd(PlbEngine* e, const int64_t* masked_ids, const int64_t* labels, const int64_t* token_ids,
+                            const int32_t* lengths, const int32_t* idx_offsets, const int32_t* idx_flat, int32_t n_masked,
+                            int32_t B, int32_t S, float* loss, float* loss_parts, void* stream) {
+  return loss_impl(e, false, masked_ids, labels, token_ids, lengths, idx_offsets, idx_flat, n_masked, B, S, loss, loss_parts,
+                   stream);
+}
+
+// ---- data-parallel exchange -------------------------------------------------------------------------------------
+extern "C" int plb_comm_unique_id(uint8_t id[PLB_COMM_ID_BYTES]) {
+  if (!id) return fail("plb_comm_unique_id: null argument");
+  if (const char* err = rccl_load()) return fail("plb_comm_unique_id: %s", err);
+  RcclId u;
+  memset(&u, 0, sizeof(u));
+  const int rc = g_rccl.GetUniqueId(&u);
+  if (rc != kNcclSuccess) return fail("ncclGetUniqueId: %s", g_rccl.GetErrorString(rc));
+  static_assert(sizeof(u) == PLB_COMM_ID_BYTES, "unique id size");
+  memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+extern "C" int plb_comm_destroy(PlbEngine* e) {
+  if (!e) return fail("plb_comm_destroy: null engine");
+  if (e->comm_stream) (void)hipStreamSynchronize(e->comm_stream);
+  if (e->comm && g_rccl.ok) (void)g_rccl.CommDestroy(e->comm);
+  e->comm = nullptr; e->comm_rank = 0; e->comm_world = 1; e->comm_pending = false;
+  if (e->ev_piece) { (void)hipEventDestroy(e->ev_piece); e->ev_piece = nullptr; }
+  if (e->ev_comm_done) { (void)hipEventDestroy(e->ev_comm_done); e->ev_comm_done = nullptr; }
+  if (e->comm_stream) { (void)hipStreamDestroy(e->comm_stream); e->comm_stream = nullptr; }
+  return 0;
+}
+
+extern "C" int plb_comm_init(PlbEngine* e, const uint8_t id[PLB_COMM_ID_BYTES], int32_t rank, int32_t world) {
+  if (!e || !id) return fail("plb_comm_init: null argument");
+  if (!e->grads) return fail("plb_comm_init: bind the gradient buffer first (plb_bind)");
+  if (world < 1 || rank < 0 || rank >= world) return fail("plb_comm_init: rank %d of %d", rank, world);
+  if (e->comm) return fail("plb_comm_init: the engine already has a communicator");
+  if (const char* err = rccl_load()) return fail("plb_comm_init: %s", err);
+  // priority stream: the collective's few workgroups should get CUs ahead of the next GEMM's grid
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  HIPTRY(hipStreamCreateWithPriority(&e->comm_stream, hipStreamNonBlocking, hi));
+  HIPTRY(hipEventCreateWithFlags(&e->ev_piece, hipEventDisableTiming));
+  HIPTRY(hipEventCreateWithFlags(&e->ev_comm_done, hipEventDisableTiming));
+  RcclId u;
+  memcpy(&u, id, sizeof(u));
+  const int rc = g_rccl.CommInitRank(&e->comm, world, u, rank);
+  if (rc != kNcclSuccess) {
+    e->comm = nullptr;
+    (void)plb_comm_destroy(e);
+    return fail("ncclCommInitRank(rank %d of %d): %s", rank, world, g_rccl.GetErrorString(rc));
+  }
+  e->comm_rank = rank; e->comm_world = world;
+  return 0;
+}
+
+extern "C" int plb_comm_info(const PlbEngine* e, int32_t* rank, int32_t* world, int32_t* rccl_version) {
+  if (!e) return fail("plb_comm_info: null engine");
+  if (rank) *rank = e->comm_rank;
+  if (world) *world = e->comm ? e->comm_world : 1;
+  if (rccl_version) {
+    int v = 0;
+    if (g_rccl.ok) (void)g_rccl.GetVersion(&v);
+    *rccl_version = v;
+  }
+  return 0;
+}
+
+extern "C" int plb_set_grad_overlap(PlbEngine* e, int32_t overlap) {
+  if (!e) return fail("plb_set_grad_overlap: null engine");
+  e->overlap = overlap != 0;
+  return 0;
+}
+
+extern "C" int plb_broadcast_params(PlbEngine* e, int32_t root, void* stream) {
+  if (!e || !e->ws) return fail("plb_broadcast_params: engine not bound");
+  if (!e->comm) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = g_rccl.Broadcast(e->params, e->params, (size_t)e->ptotal, kNcclFloat32, root, e->comm, s);
+  if (rc != kNcclSuccess) return fail("ncclBroadcast: %s", g_rccl.GetErrorString(rc));
+  return plb_sync_weights(e, stream);
+}
+
+extern "C" int plb_allreduce_grads(PlbEngine* e, void* stream) {
+  if (!e || !e->ws) return fail("plb_allreduce_grads: engine not bound");
+  if (!e->comm) return 0;
+  if (!e->grads) return fail("plb_allreduce_grads: no gradient buffer bound");
+  hipStream_t s = (hipStream_t)stream;
+  if (e->comm_pending) {  // the loss call issued the pieces: join them
+    HIPTRY(hipStreamWaitEvent(s, e->ev_comm_done, 0));
+    e->comm_pending = false;
+    return 0;
+  }
+  if (e->grads_reduced) return 0;
+  int rc = g_rccl.AllReduce(e->grads, e->grads, (size_t)e->ptrain, kNcclFloat32, kNcclSum, e->comm, s);
+  if (rc == kNcclSuccess && e->tok_grads_live) {
+    const int64_t o = e->poff[PLB_TOK_W];
+    rc = g_rccl.AllReduce(e->grads + o, e->grads + o, (size_t)(e->ptotal - o), kNcclFloat32, kNcclSum, e->comm, s);
+  }
+  if (rc != kNcclSuccess) return fail("ncclAllReduce: %s", g_rccl.GetErrorString(rc));
+  e->grads_reduced = true;
+  return 0;
+}
+
+extern "C" int32_t plb_token_head_steps(const PlbEngine* e) { return e ? e->tok_steps : -1; }
+extern "C" int plb_set_token_head_steps(PlbEngine* e, int32_t steps) {
+  if (!e || steps < 0) return fail("plb_set_token_head_steps: bad argument");
+  e->tok_steps = steps;
+  return 0;
+}
+
+extern "C" int plb_apply_mask(const int64_t* ids, const int32_t* sample_off, const int32_t* word_off,
+                              const int32_t* word_begin, const int32_t* word_len, const int8_t* action, const int64_t* repl,
+                              const int64_t* word_token, int64_t sep_token, const int32_t* crop_start, int32_t B, int32_t S,
+                              int32_t mask_id, int64_t* labels, int64_t* masked, int64_t* tokens, int32_t* lengths_out,
+                              int32_t* idx_offsets, int32_t* idx_flat, int32_t* scratch, void* stream) {
+  if (!ids || !sample_off || !word_off || !word_begin || !word_len || !action || !repl || !crop_start || !labels || !masked ||
+      !lengths_out || !idx_offsets || !idx_flat || !scratch)
+    return fail("plb_apply_mask: null argument");
+  if ((tokens != nullptr) != (word_token != nullptr)) return fail("plb_apply_mask: tokens and word_token go together");
+  if (S < 1 || S > 1024 || B < 1 || B > 1024) return fail("plb_apply_mask: needs 1 <= S <= 1024, 1 <= B <= 1024");
+  PlbApplyMask m;
+  memset(&m, 0, sizeof(m));
+  m.ids = ids; m.sample_off = sample_off; m.word_off = word_off; m.word_begin = word_begin; m.word_len = word_len;
+  m.action = action; m.repl = repl; m.word_token = word_token; m.sep_token = sep_token; m.crop_start = crop_start;
+  m.B = B; m.S = S; m.mask_id = mask_id;
+  m.labels = labels; m.masked = masked; m.tokens = tokens; m.lengths_out = lengths_out;
+  m.counts = scratch; m.idx_padded = scratch + B; m.offsets = idx_offsets; m.flat = idx_flat;
+  TRY(plb_launch_apply_mask(&m, (hipStream_t)stream));
+  return 0;
 }
 
 extern "C" int plb_mask_batch(const int64_t* labels, const int32_t* lengths, int32_t B, int32_t S, uint64_t seed,
@@ -759,14 +1047,22 @@ extern "C" int plb_mask_batch(const int64_t* labels, const int32_t* lengths, int
 extern "C" int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, float eps, float weight_decay,
                               int32_t step, float grad_scale, void* stream) {
   if (!e || !e->ws || !e->grads || !e->m || !e->v) return fail("plb_adamw_step: optimizer buffers not bound");
+  if (e->infer) return fail("plb_adamw_step: inference-only engine");
   if (step < 1) return fail("plb_adamw_step: step counts from 1");
   hipStream_t s = (hipStream_t)stream;
+  if (e->comm_pending) {  // all-reduce pieces still in flight on the communication stream
+    HIPTRY(hipStreamWaitEvent(s, e->ev_comm_done, 0));
+    e->comm_pending = false;
+  }
   TRY(plb_launch_adamw(e->params, e->grads, e->m, e->v, e->at<bf16_t>(e->o_wbf), (size_t)e->ptrain, lr, beta1, beta2, eps,
                        weight_decay, step, grad_scale, s));
-  if (e->tok_grads_live) {  // token head: trained only by dual-head steps (no gradient, no update — as the pooler)
+  if (e->tok_grads_live) {
+    // token head: trained only by dual-head steps (no gradient, no update — as the pooler), with its OWN step count:
+    // torch.optim.AdamW keeps one per parameter, so a head that starts training late gets its own bias correction
     const int64_t o = e->poff[PLB_TOK_W];
+    e->tok_steps += 1;
     TRY(plb_launch_adamw(e->params + o, e->grads + o, e->m + o, e->v + o, e->at<bf16_t>(e->o_wbf) + o,
-                         (size_t)(e->ptotal - o), lr, beta1, beta2, eps, weight_decay, step, grad_scale, s));
+                         (size_t)(e->ptotal - o), lr, beta1, beta2, eps, weight_decay, e->tok_steps, grad_scale, s));
   }
   return sync_transposes(e, s);
 }

@@ -506,7 +506,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
           if (ACT == 4) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float gq = (n0 + r < p.ce_cols) ? __expf(v[r] - ce_l) * ce_wt : 0.f;
+              // select, never 0 * exp(): rows without loss (w = 0: padding, positions past the length) hold live or
+              // stale hidden states whose logit could overflow the exponential
+              float gq = (ce_wt != 0.f && n0 + r < p.ce_cols) ? __expf(v[r] - ce_l) * ce_wt : 0.f;
               gq -= (n0 + r == ce_t) ? ce_wt : 0.f;
               v[r] = gq;
             }
@@ -515,9 +517,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
             v[0] += bf_lo(rr[nh][ni].x); v[1] += bf_hi(rr[nh][ni].x);
             v[2] += bf_lo(rr[nh][ni].y); v[3] += bf_hi(rr[nh][ni].y);
           }
-          if (ACT == 2) {  // gelu backward: multiply by gelu_new'(u)
-            v[0] *= gelu_new_grad_f(bf_lo(ux[nh][ni].x)); v[1] *= gelu_new_grad_f(bf_hi(ux[nh][ni].x));
-            v[2] *= gelu_new_grad_f(bf_lo(ux[nh][ni].y)); v[3] *= gelu_new_grad_f(bf_hi(ux[nh][ni].y));
+          if (ACT == 2) {  // gelu backward: multiply by gelu_new'(u); exact zeros stay zeros whatever u holds
+            v[0] = v[0] != 0.f ? v[0] * gelu_new_grad_f(bf_lo(ux[nh][ni].x)) : 0.f;
+            v[1] = v[1] != 0.f ? v[1] * gelu_new_grad_f(bf_hi(ux[nh][ni].x)) : 0.f;
+            v[2] = v[2] != 0.f ? v[2] * gelu_new_grad_f(bf_lo(ux[nh][ni].y)) : 0.f;
+            v[3] = v[3] != 0.f ? v[3] * gelu_new_grad_f(bf_hi(ux[nh][ni].y)) : 0.f;
           }
           if (OUTF32) {
             if (st) *(float4*)(p.Cf + (size_t)m * p.ldcf + n0) = make_float4(v[0], v[1], v[2], v[3]);

@@ -19,8 +19,8 @@ DEVI f32x4 nt_epilogue(const PlbGemmNT& p, f32x4 v, int m, int n0) {
   }
   if (ACT == 2) {  // gelu backward: multiply by gelu_new'(u)
     uint2 u = *(const uint2*)(p.aux + (size_t)m * p.ldaux + n0);
-    v[0] *= gelu_new_grad_f(bf_lo(u.x)); v[1] *= gelu_new_grad_f(bf_hi(u.x));
-    v[2] *= gelu_new_grad_f(bf_lo(u.y)); v[3] *= gelu_new_grad_f(bf_hi(u.y));
+    v[0] = v[0] != 0.f ? v[0] * gelu_new_grad_f(bf_lo(u.x)) : 0.f; v[1] = v[1] != 0.f ? v[1] * gelu_new_grad_f(bf_hi(u.x)) : 0.f;
+    v[2] = v[2] != 0.f ? v[2] * gelu_new_grad_f(bf_lo(u.y)) : 0.f; v[3] = v[3] != 0.f ? v[3] * gelu_new_grad_f(bf_hi(u.y)) : 0.f;
   }
   if (OUTF32) {
     *(float4*)(p.Cf + (size_t)m * p.ldcf + n0) = make_float4(v[0], v[1], v[2], v[3]);

@@ -99,6 +99,63 @@ __global__ __launch_bounds__(512) void mask_words_kernel(PlbMask p) {
   if (i == 0) p.counts[b] = total;
 }
 
+// ---- bit-exact application of host-drawn decisions (dataloader.py:59-137) ------------------------------------------
+// One workgroup per sample. Pass 1: every output position copies its uncropped source id (labels = masked = id,
+// token = separator token; zero past the length). Pass 2: one thread per word rewrites the positions of its word
+// that fall inside the crop window (mask id / replacement id; the word's token id) and flags the modified ones.
+// Pass 3: the flags are compacted into the ascending index list (re-based to the crop by construction).
+__global__ __launch_bounds__(256) void apply_mask_kernel(PlbApplyMask p) {
+  __shared__ unsigned char flag[1024];
+  __shared__ int wcnt[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int S = p.S;
+  const int base = p.sample_off[b], n = p.sample_off[b + 1] - base;
+  const int start = p.crop_start[b];
+  int len = n - start;
+  len = len > S ? S : (len < 0 ? 0 : len);
+  for (int i = tid; i < S; i += 256) {
+    const long long id = i < len ? p.ids[base + start + i] : 0;
+    p.labels[(size_t)b * S + i] = id;
+    p.masked[(size_t)b * S + i] = id;
+    if (p.tokens) p.tokens[(size_t)b * S + i] = i < len ? p.sep_token : 0;
+    flag[i] = 0;
+  }
+  if (tid == 0) p.lengths_out[b] = len;
+  __syncthreads();
+  const int w0 = p.word_off[b], nw = p.word_off[b + 1] - w0;
+  for (int k = tid; k < nw; k += 256) {
+    const int wb = p.word_begin[w0 + k], wl = p.word_len[w0 + k], act = p.action[w0 + k];
+    const long long tk = p.word_token ? p.word_token[w0 + k] : 0;
+    if (act == 0 && !p.tokens) continue;
+    for (int q = 0; q < wl; ++q) {
+      const int i = wb + q - start;
+      if (i < 0 || i >= len) continue;
+      if (act == 1) p.masked[(size_t)b * S + i] = p.mask_id;
+      else if (act == 2) p.masked[(size_t)b * S + i] = p.repl[base + wb + q];
+      if (act != 0) flag[i] = 1;
+      if (p.tokens) p.tokens[(size_t)b * S + i] = tk;
+    }
+  }
+  __syncthreads();
+  int run = 0;  // modified positions before the current 256-position chunk
+  for (int c0 = 0; c0 < S; c0 += 256) {
+    const int i = c0 + tid;
+    const bool mod = i < S && flag[i];
+    const unsigned long long mm = __builtin_amdgcn_ballot_w64(mod);
+    if (lane == 0) wcnt[w] = __builtin_popcountll(mm);
+    __syncthreads();
+    int pos = run + __builtin_popcountll(mm & ((1ull << lane) - 1ull)), tot = 0;
+    for (int k = 0; k < 4; ++k) {
+      if (k < w) pos += wcnt[k];
+      tot += wcnt[k];
+    }
+    if (mod) p.idx_padded[(size_t)b * S + pos] = i;
+    run += tot;
+    __syncthreads();
+  }
+  if (tid == 0) p.counts[b] = run;
+}
+
 // offsets = exclusive scan of counts (B <= 1024); flat = concatenation of the per-sample lists.
 __global__ __launch_bounds__(1024) void mask_compact_kernel(PlbMask p) {
   __shared__ int sc[1024];
@@ -121,6 +178,15 @@ __global__ __launch_bounds__(1024) void mask_compact_kernel(PlbMask p) {
 }
 
 }  // namespace
+
+extern "C" int plb_launch_apply_mask(const PlbApplyMask* p, hipStream_t stream) {
+  if (p->S < 1 || p->S > 1024 || p->B < 1 || p->B > 1024) return 1;
+  hipLaunchKernelGGL(apply_mask_kernel, dim3(p->B), dim3(256), 0, stream, *p);
+  PlbMask m = PlbMask();  // CSR compaction shared with the Philox fast mode
+  m.B = p->B; m.S = p->S; m.counts = p->counts; m.idx_padded = p->idx_padded; m.offsets = p->offsets; m.flat = p->flat;
+  hipLaunchKernelGGL(mask_compact_kernel, dim3(1), dim3(1024), 0, stream, m);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}
 
 extern "C" int plb_launch_mask(const PlbMask* p, hipStream_t stream) {
   if (p->S < 1 || p->S > 512 || p->B < 1 || p->B > 1024) return 1;

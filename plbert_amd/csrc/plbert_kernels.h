@@ -86,7 +86,7 @@ typedef struct {
   float *mean, *rstd;           // [T]
   int T, H;
   int Tzero;                    // backward: rows T..Tzero-1 of dx are written as zeros
-  // backward: dx = LN'(dy); partials[nblocks][2H] = dgamma | dbeta
+  // backward: dx = LN'(dy); partials[nblocks][3H] = dgamma | dbeta | column sums of dx (as stored)
   const bf16_t* dy; int lddy;
   bf16_t* dx; int lddx;
   float* partials; int nblocks;
@@ -98,6 +98,13 @@ int plb_launch_ln_bwd(const PlbLayerNorm* p, hipStream_t stream);
 // Only the first Nout (<= N) sums are written to out.
 int plb_launch_colsum(const void* X, int is_bf16, size_t R, int N, int ld, float* out, int Nout, int accumulate,
                       float* scratch, int nsplit, hipStream_t stream);
+
+// out[0..Nout) = column sums [col0, col0+Nout) finished from the [nsplit][N] partial rows a plb_launch_colsum left in scratch
+int plb_launch_copy_cols(const float* scratch, int nsplit, int N, int col0, int Nout, float* out, hipStream_t stream);
+
+// pooled[b,:] = tanh(W[H,H] · hidden[b*S*H ..] + bias)  (first token of every sample, fp32)
+int plb_launch_pooler(const float* hidden, int B, int S, int H, const float* W, const float* bias, float* pooled,
+                      hipStream_t stream);
 
 // Attention over the fused qkv buffer [T,3H] (Q | K | V, head h at columns h*64..h*64+63), head_dim 64.
 typedef struct {
@@ -146,6 +153,15 @@ typedef struct {
   int64_t* masked; int32_t *counts, *idx_padded, *offsets, *flat;
 } PlbMask;
 int plb_launch_mask(const PlbMask* p, hipStream_t stream);
+
+// Bit-exact application of host-drawn masking decisions (mask.hip; include/plbert.h plb_apply_mask)
+typedef struct {
+  const int64_t* ids; const int32_t *sample_off, *word_off, *word_begin, *word_len; const int8_t* action;
+  const int64_t* repl; const int64_t* word_token; int64_t sep_token; const int32_t* crop_start;
+  int B, S, mask_id;
+  int64_t *labels, *masked, *tokens; int32_t *lengths_out, *counts, *idx_padded, *offsets, *flat;
+} PlbApplyMask;
+int plb_launch_apply_mask(const PlbApplyMask* p, hipStream_t stream);
 
 // AdamW (torch.optim.AdamW semantics) over a flat range; also refreshes the bf16 compute copy.
 int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, float lr, float beta1,

@@ -86,6 +86,9 @@ __global__ __launch_bounds__(256) void embed_kernel(PlbEmbed p) {
 // (collects the tokens whose id is v into an LDS list, then sums their dx rows in token order), block
 // V + s owns position row s (sum over the batch). Row 0 of the word table is the padding row
 // (nn.Embedding(padding_idx=0), modeling_albert.py:56): no gradient.
+// The token range is walked in chunks of EMB_CHUNK tokens so the list fits LDS for any T (configs/config.yml:16
+// is 96 x 512 = 49,152 tokens on one GPU).
+constexpr int EMB_CHUNK = 32768;
 __global__ __launch_bounds__(256) void embed_scatter_kernel(PlbEmbed p, int P) {
   extern __shared__ int list[];  // 4 per-wave segments of matching token indices
   __shared__ int wcnt[4];
@@ -100,35 +103,38 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(PlbEmbed p, int P) {
     s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
   };
   if (row < p.V) {
-    // each wave scans its own quarter of the tokens (64-token chunks, round-robin) and appends the
-    // matches to its own list segment: no block barrier inside the scan. Fixed order -> deterministic.
+    // each wave scans its own quarter of the chunk (64-token pieces, round-robin) and appends the matches to its
+    // own list segment: no block barrier inside the scan. Fixed order -> deterministic.
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int cap = (T + 3) / 4 + 64;
-    int cnt = 0;
-    if (row != 0) {
-      for (int t0 = w * 64; t0 < T; t0 += 256) {
+    const int chunk = T < EMB_CHUNK ? T : EMB_CHUNK;
+    const int cap = (chunk + 3) / 4 + 64;
+    for (int c0 = 0; c0 < T && row != 0; c0 += EMB_CHUNK) {
+      const int c1 = c0 + EMB_CHUNK < T ? c0 + EMB_CHUNK : T;
+      int cnt = 0;
+      for (int t0 = c0 + w * 64; t0 < c1; t0 += 256) {
         const int t = t0 + lane;
-        const bool hit = t < T && p.ids[t] == row;
+        const bool hit = t < c1 && p.ids[t] == row;
         const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
         if (hit) list[w * cap + cnt + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = t;
         cnt += __builtin_popcountll(m);
       }
-    }
-    if (lane == 0) wcnt[w] = cnt;
-    __syncthreads();
-    // a few ids (separator, mask) own thousands of tokens: ngrp row groups x 4 loads in flight each
-    for (int ww = 0; ww < 4; ++ww) {
-      const int n = wcnt[ww];
-      const int* l = list + ww * cap;
-      int i = grp;
-      for (; i + 3 * ngrp < n; i += 4 * ngrp) {
-        const int t0 = l[i], t1 = l[i + ngrp], t2 = l[i + 2 * ngrp], t3 = l[i + 3 * ngrp];
-        const float4 v0 = *(const float4*)(p.dx + (size_t)t0 * E + 4 * q), v1 = *(const float4*)(p.dx + (size_t)t1 * E + 4 * q);
-        const float4 v2 = *(const float4*)(p.dx + (size_t)t2 * E + 4 * q), v3 = *(const float4*)(p.dx + (size_t)t3 * E + 4 * q);
-        s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
-        s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+      if (lane == 0) wcnt[w] = cnt;
+      __syncthreads();
+      // a few ids (separator, mask) own thousands of tokens: ngrp row groups x 4 loads in flight each
+      for (int ww = 0; ww < 4; ++ww) {
+        const int n = wcnt[ww];
+        const int* l = list + ww * cap;
+        int i = grp;
+        for (; i + 3 * ngrp < n; i += 4 * ngrp) {
+          const int t0 = l[i], t1 = l[i + ngrp], t2 = l[i + 2 * ngrp], t3 = l[i + 3 * ngrp];
+          const float4 v0 = *(const float4*)(p.dx + (size_t)t0 * E + 4 * q), v1 = *(const float4*)(p.dx + (size_t)t1 * E + 4 * q);
+          const float4 v2 = *(const float4*)(p.dx + (size_t)t2 * E + 4 * q), v3 = *(const float4*)(p.dx + (size_t)t3 * E + 4 * q);
+          s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+          s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; i < n; i += ngrp) add(l[i]);
       }
-      for (; i < n; i += ngrp) add(l[i]);
+      __syncthreads();  // the lists are rewritten by the next chunk
     }
   } else {
     const int sidx = row - p.V;  // position row: sum over the batch
@@ -215,18 +221,18 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(PlbLayerNorm p) {
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
-  __shared__ float red[4][2][NCH * 256];
+  __shared__ float red[4][3][NCH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int H = p.H;
   const float invH = 1.0f / (float)H;
-  float dg[NCH][4], db[NCH][4], gm[NCH][4];
+  float dg[NCH][4], db[NCH][4], gm[NCH][4], dxs[NCH][4];
 #pragma unroll
   for (int i = 0; i < NCH; ++i) {
     const int c = (lane + 64 * i) * 4;
     float4 g = (c < H) ? *(const float4*)(p.gamma + c) : make_float4(0, 0, 0, 0);
     gm[i][0] = g.x; gm[i][1] = g.y; gm[i][2] = g.z; gm[i][3] = g.w;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = 0.f;
+    for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = dxs[i][j] = 0.f;
   }
   for (int t0 = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * LN_R; t0 < p.T; t0 += gridDim.x * 4 * LN_R) {
     uint2 ux[LN_R][NCH], ud[LN_R][NCH];
@@ -270,6 +276,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
           o.x = pack_bf2(rstd[r] * (dxh[i][0] - s1 - xh[i][0] * s2), rstd[r] * (dxh[i][1] - s1 - xh[i][1] * s2));
           o.y = pack_bf2(rstd[r] * (dxh[i][2] - s1 - xh[i][2] * s2), rstd[r] * (dxh[i][3] - s1 - xh[i][3] * s2));
           *(uint2*)(p.dx + (size_t)t * p.lddx + c) = o;
+          // column sums of dx as stored: the bias gradient of the Linear whose output this LayerNorm normalised
+          dxs[i][0] += bf_lo(o.x); dxs[i][1] += bf_hi(o.x); dxs[i][2] += bf_lo(o.y); dxs[i][3] += bf_hi(o.y);
         }
       }
     }
@@ -287,13 +295,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
     const int c = (lane + 64 * i) * 4;
     if (c < H) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { red[wave][0][c + j] = dg[i][j]; red[wave][1][c + j] = db[i][j]; }
+      for (int j = 0; j < 4; ++j) { red[wave][0][c + j] = dg[i][j]; red[wave][1][c + j] = db[i][j]; red[wave][2][c + j] = dxs[i][j]; }
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * H; i += 256) {
+  for (int i = threadIdx.x; i < 3 * H; i += 256) {  // partials[block][dgamma | dbeta | colsum(dx)]
     const int which = i / H, col = i % H;
-    p.partials[(size_t)blockIdx.x * 2 * H + i] =
+    p.partials[(size_t)blockIdx.x * 3 * H + i] =
         red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
   }
 }
@@ -373,13 +381,13 @@ __global__ void reduce_slabs_kernel(const float* slab, int splits, size_t n, flo
 }
 
 __global__ __launch_bounds__(256) void reduce_cols_kernel(const float* scratch, int nsplit, int N, int Nout, float* out,
-                                                          int accumulate) {
+                                                          int accumulate, int col0) {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + c;
   float s = 0.f;
   if (j < Nout)
-    for (int k = g; k < nsplit; k += 4) s += scratch[(size_t)k * N + j];  // fixed order per column
+    for (int k = g; k < nsplit; k += 4) s += scratch[(size_t)k * N + col0 + j];  // fixed order per column
   red[g][c] = s;
   __syncthreads();
   if (g == 0 && j < Nout) {
@@ -545,6 +553,22 @@ __global__ void transpose_cast_kernel(const float* src, int R, int C, bf16_t* ds
     if (c < C && r < R) dst[(size_t)c * ldd + r] = f2bf(tile[tx][k]);
   }
 }
+// AlbertModel pooler (modeling_albert.py:403): one wave per output feature, fp32 dot over H, tanh.
+__global__ __launch_bounds__(256) void pooler_kernel(const float* hidden, int S, int H, const float* W, const float* bias,
+                                                     float* pooled) {
+  const int b = blockIdx.y, lane = threadIdx.x & 63;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= H) return;
+  const float* x = hidden + (size_t)b * S * H;
+  const float* w = W + (size_t)o * H;
+  float s = 0.f;
+  for (int k = lane * 4; k < H; k += 256) {
+    const float4 a = *(const float4*)(x + k), c = *(const float4*)(w + k);
+    s += a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w;
+  }
+  s = wave_sum(s);
+  if (lane == 0) pooled[(size_t)b * H + o] = tanhf(s + bias[o]);
+}
 __global__ void bf16_to_f32_kernel(const bf16_t* src, int lds_, float* dst, int ldd, int R, int C) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)R * C) return;
@@ -571,9 +595,10 @@ extern "C" int plb_launch_embed_fwd(const PlbEmbed* p, hipStream_t stream) {
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_embed_scatter(const PlbEmbed* p, int P, hipStream_t stream) {
-  if ((p->E != 64 && p->E != 128 && p->E != 256) || p->T <= 0 || (size_t)p->T * 4 > 150 * 1024) return 1;
+  if ((p->E != 64 && p->E != 128 && p->E != 256) || p->T <= 0) return 1;
   ProfScope ps(PLB_K_EMBED_BWD, stream, 0, (double)p->T * p->E * 8.0);
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(p->V + P), dim3(256), (size_t)(((p->T + 3) / 4 + 64) * 4) * 4, stream, *p, P);
+  const int chunk = p->T < EMB_CHUNK ? p->T : EMB_CHUNK;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(p->V + P), dim3(256), (size_t)(((chunk + 3) / 4 + 64) * 4) * 4, stream, *p, P);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_embed_bwd(const PlbEmbed* p, hipStream_t stream) {
@@ -625,7 +650,16 @@ extern "C" int plb_launch_colsum(const void* X, int is_bf16, size_t R, int N, in
   else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, stream, X, R, N, ld, scratch, nsplit);
   if (hipGetLastError() != hipSuccess) return 2;
   hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)((Nout + 63) / 64)), dim3(256), 0, stream, scratch, nsplit, N,
-                     Nout, out, accumulate);
+                     Nout, out, accumulate, 0);
+  return LAUNCH_OK();
+}
+// Second half of a column sum whose first half (plb_launch_colsum) left [nsplit][N] partial rows in scratch:
+// out[0..Nout) = sums of columns [col0, col0 + Nout). Lets one pass over a matrix feed two gradient tensors.
+extern "C" int plb_launch_copy_cols(const float* scratch, int nsplit, int N, int col0, int Nout, float* out,
+                                    hipStream_t stream) {
+  if (nsplit <= 0 || col0 < 0 || col0 + Nout > N) return 1;
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)((Nout + 63) / 64)), dim3(256), 0, stream, scratch, nsplit, N,
+                     Nout, out, 0, col0);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_gather_rows(const bf16_t* src, int lds_, const int32_t* rows, int n, int npad, int H,
@@ -693,6 +727,12 @@ extern "C" int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hip
 extern "C" int plb_launch_transpose_cast(const float* src, int R, int C, bf16_t* dst, int ldd, hipStream_t stream) {
   ProfScope ps(PLB_K_CAST, stream, 0, 6.0 * (double)R * C);
   hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, src, R, C, dst, ldd);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_pooler(const float* hidden, int B, int S, int H, const float* W, const float* bias, float* pooled,
+                                 hipStream_t stream) {
+  if (H % 4 || B < 1 || S < 1) return 1;
+  hipLaunchKernelGGL(pooler_kernel, dim3((H + 3) / 4, B), dim3(256), 0, stream, hidden, S, H, W, bias, pooled);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_bf16_to_f32(const bf16_t* src, int lds_, float* dst, int ldd, int R, int C, hipStream_t stream) {

@@ -53,33 +53,70 @@ class MaskedPhonemeDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.data)
 
-    def _draw(self, words, pool_ids):
-        """Per-word decisions in reference RNG order -> (labels, masked, index) as id lists."""
+    def _decide(self, words, pool_ids):
+        """The reference's random draws for one document, in the reference's order, as DECISIONS:
+        (ids, word_begin, word_len, action, repl) with ``ids`` the uncropped labels (a separator after each
+        word), ``action[w]`` 0 keep / 1 mask / 2 replace, ``repl`` the replacement ids at the positions of
+        replaced words (0 elsewhere). Applying them is integer work — here (``_apply``) or on the device
+        (plb_apply_mask)."""
         index_word = self.char_indexer
-        labels, masked, index = [], [], []
+        ids_all, begin, length, action, repl = [], [], [], [], []
         n_pool = len(pool_ids)
         for w in words:
             ids = index_word(w)
             n = len(ids)
-            start = len(masked)
-            labels.extend(ids)
-            labels.append(SEPARATOR_ID)
+            begin.append(len(ids_all))
+            length.append(n)
+            act = 0
+            r = [0] * n
             if np.random.rand() < self.word_pred_prob:                       # dataloader.py:85
-                action = _ACTIONS[int(np.random.choice(3, p=self._probs))]  # dataloader.py:89
-                if action == "replace":
+                a = _ACTIONS[int(np.random.choice(3, p=self._probs))]       # dataloader.py:89
+                if a == "replace":
                     # random.choices(pool, k=n) draws floor(random() * len(pool)) n times (dataloader.py:94)
                     picks = random.choices(range(n_pool), k=n) if n else []
-                    masked.extend(pool_ids[i] for i in picks)
-                elif action == "mask":
-                    masked.extend([MASK_ID] * n)
-                else:
-                    masked.extend(ids)
-                if action != "no_change":
-                    index.extend(range(start, start + n))                    # separator never indexed
-            else:
-                masked.extend(ids)
-            masked.append(SEPARATOR_ID)
-        return labels, masked, index
+                    r = [pool_ids[i] for i in picks]
+                    act = 2
+                elif a == "mask":
+                    act = 1
+            action.append(act)
+            ids_all.extend(ids)
+            ids_all.append(SEPARATOR_ID)
+            repl.extend(r)
+            repl.append(0)
+        return ids_all, begin, length, action, repl
+
+    @staticmethod
+    def _apply(ids_all, begin, length, action, repl):
+        """Decisions -> (labels, masked, index) id lists (dataloader.py:66-104; the separator is never indexed)."""
+        masked = list(ids_all)
+        index = []
+        for b, n, a in zip(begin, length, action):
+            if a == 1:
+                masked[b:b + n] = [MASK_ID] * n
+            elif a == 2:
+                masked[b:b + n] = repl[b:b + n]
+            if a:
+                index.extend(range(b, b + n))
+        return list(ids_all), masked, index
+
+    def decisions(self, idx):
+        """Everything ``__getitem__`` draws for row ``idx`` — consuming the global streams exactly as it does — without
+        applying it: a dict of int arrays for ``device_apply_mask`` (plb_apply_mask does the integer work on the GPU).
+        ``length`` is the sample's collated length min(n, max_seq_length)."""
+        row = self.data[idx]
+        words = row["phonemes"]
+        pool_ids = self.char_indexer("".join(words))
+        ids_all, begin, length, action, repl = self._decide(words, pool_ids)
+        n = len(ids_all)
+        start = 0
+        if n > self.max_seq_length:                                         # dataloader.py:110-112
+            start = int(np.random.randint(0, n - self.max_seq_length))
+        tok = row["token_ids"] if self.use_token_ids else None
+        return {"ids": np.asarray(ids_all, dtype=np.int64), "word_begin": np.asarray(begin, dtype=np.int32),
+                "word_len": np.asarray(length, dtype=np.int32), "action": np.asarray(action, dtype=np.int8),
+                "repl": np.asarray(repl, dtype=np.int64), "crop_start": start,
+                "length": min(n, self.max_seq_length),
+                "word_token": None if tok is None else np.asarray(tok, dtype=np.int64)[: len(words)]}
 
     def __getitem__(self, idx):
         row = self.data[idx]
@@ -87,7 +124,7 @@ class MaskedPhonemeDataset(torch.utils.data.Dataset):
         pool_ids = self.char_indexer("".join(words))  # replacement pool: the document itself
         tok = row["token_ids"] if self.use_token_ids else [self.word_separator] * len(words)
 
-        labels, masked, index = self._draw(words, pool_ids)
+        labels, masked, index = self._apply(*self._decide(words, pool_ids))
         token_ids = []
         for w, t in zip(words, tok):
             token_ids.extend([t] * len(w))
@@ -107,6 +144,26 @@ class MaskedPhonemeDataset(torch.utils.data.Dataset):
         if self.use_token_ids:
             return token_t, labels_t, masked_t, index
         return labels_t, masked_t, index
+
+
+def collate_decisions(records):
+    """The collaters' ordering (dataloader.py:204,280: sort by length, descending, stable) applied to decision
+    records, packed into the flat arrays plb_apply_mask takes. Returns a dict of numpy arrays + B, S."""
+    recs = sorted(records, key=lambda r: r["length"], reverse=True)
+    B = len(recs)
+    S = int(recs[0]["length"]) if B else 0
+    sample_off = np.zeros(B + 1, dtype=np.int32)
+    word_off = np.zeros(B + 1, dtype=np.int32)
+    for b, r in enumerate(recs):
+        sample_off[b + 1] = sample_off[b] + len(r["ids"])
+        word_off[b + 1] = word_off[b] + len(r["word_begin"])
+    cat = lambda k, dt: (np.concatenate([r[k] for r in recs]).astype(dt) if B else np.zeros(0, dt))
+    with_tok = B > 0 and recs[0]["word_token"] is not None
+    return {"B": B, "S": S, "ids": cat("ids", np.int64), "repl": cat("repl", np.int64), "sample_off": sample_off,
+            "word_off": word_off, "word_begin": cat("word_begin", np.int32), "word_len": cat("word_len", np.int32),
+            "action": cat("action", np.int8), "crop_start": np.asarray([r["crop_start"] for r in recs], dtype=np.int32),
+            "lengths": [int(r["length"]) for r in recs],
+            "word_token": cat("word_token", np.int64) if with_tok else None}
 
 
 def _pad_stack(rows, width):

@@ -18,7 +18,9 @@ from .init import param_shapes
 
 
 class HipEngine:
-    def __init__(self, cfg, num_phonemes, num_tokens=0, max_batch=32, max_seq=512, device=None):
+    def __init__(self, cfg, num_phonemes, num_tokens=0, max_batch=32, max_seq=512, device=None, train=True):
+        """``train=False``: inference / validation engine (README.md:91, train.py:288-304) — no gradient, moment or
+        per-layer activation buffers (forward and loss-only calls work, backward and AdamW raise)."""
         cfg.check_supported()
         if not torch.cuda.is_available():
             raise RuntimeError("HipEngine needs a ROCm GPU (torch.cuda.is_available() is False); "
@@ -27,11 +29,14 @@ class HipEngine:
         self.num_phonemes, self.num_tokens = int(num_phonemes), int(num_tokens)
         self.max_batch, self.max_seq = int(max_batch), int(max_seq)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.train_mode = bool(train)
         self.L = _lib.lib()
         c = _lib.PlbConfig(cfg.vocab_size, cfg.embedding_size, cfg.hidden_size, cfg.num_attention_heads,
                            cfg.intermediate_size, cfg.num_hidden_layers, cfg.max_position_embeddings,
                            cfg.type_vocab_size, cfg.layer_norm_eps, self.num_phonemes, self.num_tokens,
-                           self.max_batch, self.max_seq)
+                           self.max_batch, self.max_seq, 0 if train else 1)
         h = C.c_void_p()
         _lib.check(self.L.plb_create(C.byref(c), C.byref(h)), "plb_create")
         self.handle = h
@@ -48,18 +53,40 @@ class HipEngine:
             shp = shapes[name]
             assert int(np.prod(shp)) == sizes[i], (name, shp, sizes[i])
             self.layout[name] = (int(offs[i]), int(sizes[i]), tuple(shp))
+        # every C-ABI call below runs with this engine's device current (plb_bind creates its side stream and events
+        # there; launches go to that device's streams): HipEngine(device="cuda:1") works while cuda:0 is current
         with torch.cuda.device(self.device):
-            self.params = torch.zeros(self.total, dtype=torch.float32, device=self.device)
-            self.grads = torch.zeros(self.total, dtype=torch.float32, device=self.device)
-            self.exp_avg = torch.zeros(self.total, dtype=torch.float32, device=self.device)
-            self.exp_avg_sq = torch.zeros(self.total, dtype=torch.float32, device=self.device)
-            self.ws_bytes = int(self.L.plb_workspace_bytes(h))
-            self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
-            self._loss = torch.zeros(1, dtype=torch.float32, device=self.device)
-            self._loss_parts = torch.zeros(2, dtype=torch.float32, device=self.device)
-        _lib.check(self.L.plb_bind(h, self.params.data_ptr(), self.grads.data_ptr(), self.exp_avg.data_ptr(),
-                                   self.exp_avg_sq.data_ptr(), self.workspace.data_ptr(), self.ws_bytes), "plb_bind")
+            z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
+            self.params = z(self.total)
+            self._loss = z(1)
+            self._loss_parts = z(2)
+        # gradients, AdamW moments and the workspace are allocated by the first call that computes (_bind): a model
+        # that is only constructed, or whose parameters move into another engine (model.py: _adopt), holds its
+        # parameters and nothing else
+        self.grads = self.exp_avg = self.exp_avg_sq = self.workspace = None
+        self.ws_bytes = int(self.L.plb_workspace_bytes(h))
+        self._bound = False
         self._synced_version = -1
+        self.comm_world = 1
+
+    def _bind(self):
+        if self._bound:
+            return
+        with torch.cuda.device(self.device):
+            z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
+            if self.train_mode:
+                self.grads, self.exp_avg, self.exp_avg_sq = z(self.total), z(self.total), z(self.total)
+            self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
+            p = lambda t: None if t is None else t.data_ptr()
+            # plb_bind creates the engine's side stream and events on the current device
+            _lib.check(self.L.plb_bind(self.handle, self.params.data_ptr(), p(self.grads), p(self.exp_avg),
+                                       p(self.exp_avg_sq), self.workspace.data_ptr(), self.ws_bytes), "plb_bind")
+        self._bound = True
+
+    def device_bytes(self):
+        """Bytes of device memory this engine holds."""
+        ts = [self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.workspace]
+        return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
     def __del__(self):
         try:
@@ -91,7 +118,7 @@ class HipEngine:
             missing = [k for k in self.layout if k not in seen]
             if missing:
                 raise KeyError(f"missing keys {missing}")
-        self.sync_weights()
+        self._synced_version = -1  # the compute copies are refreshed by the next call that computes
 
     def state_dict(self):
         return OrderedDict((k, self.view(k).detach().clone()) for k in self.layout)
@@ -100,12 +127,64 @@ class HipEngine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def sync_weights(self):
-        _lib.check(self.L.plb_sync_weights(self.handle, self._stream()), "plb_sync_weights")
+        """Refresh the bf16 / transposed compute copies from the fp32 parameters. Automatic after load_state_dict,
+        AdamW and any in-place op torch tracks on the parameters; call it yourself after writing through ``.data``
+        (which bypasses torch's version counter)."""
+        self._bind()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.plb_sync_weights(self.handle, self._stream()), "plb_sync_weights")
         self._synced_version = self.params._version
 
     def _ensure_synced(self):
+        self._bind()
         if self.params._version != self._synced_version:
             self.sync_weights()
+
+    # ---- data-parallel exchange (plb_comm_*) ------------------------------------------------------------
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """Attach an RCCL communicator (collective: every rank calls it with rank 0's ``comm_unique_id()``)."""
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._bind()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.plb_comm_init(self.handle, buf, int(rank), int(world)), "plb_comm_init")
+        self.comm_world = int(world)
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _lib.check(_lib.lib().plb_comm_unique_id(buf), "plb_comm_unique_id")
+        return bytes(buf)
+
+    def comm_info(self):
+        r, w, v = C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self.L.plb_comm_info(self.handle, C.byref(r), C.byref(w), C.byref(v)), "plb_comm_info")
+        return int(r.value), int(w.value), int(v.value)
+
+    def comm_destroy(self):
+        with torch.cuda.device(self.device):
+            self.L.plb_comm_destroy(self.handle)
+        self.comm_world = 1
+
+    def set_grad_overlap(self, on):
+        _lib.check(self.L.plb_set_grad_overlap(self.handle, int(bool(on))), "plb_set_grad_overlap")
+
+    def broadcast_params(self, root=0):
+        self._bind()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.plb_broadcast_params(self.handle, int(root), self._stream()), "plb_broadcast_params")
+        self._synced_version = self.params._version
+
+    def allreduce_grads(self):
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.plb_allreduce_grads(self.handle, self._stream()), "plb_allreduce_grads")
+
+    @property
+    def token_head_steps(self):
+        return int(self.L.plb_token_head_steps(self.handle))
+
+    @token_head_steps.setter
+    def token_head_steps(self, n):
+        _lib.check(self.L.plb_set_token_head_steps(self.handle, int(n)), "plb_set_token_head_steps")
 
     # ---- calls --------------------------------------------------------------------------------------------
     def _dev_i64(self, x):
@@ -133,10 +212,24 @@ class HipEngine:
             hid = torch.empty((B, S, self.cfg.hidden_size), dtype=torch.float32, device=self.device) if want_hidden else None
             ph = torch.empty((B, S, self.num_phonemes), dtype=torch.float32, device=self.device) if want_phoneme else None
             tk = torch.empty((B, S, self.num_tokens), dtype=torch.float32, device=self.device) if want_token else None
-        p = lambda t: None if t is None else t.data_ptr()
-        _lib.check(self.L.plb_forward(self.handle, ids.data_ptr(), p(lens), B, S, p(hid), p(ph), p(tk), self._stream()),
-                   "plb_forward")
+            p = lambda t: None if t is None else t.data_ptr()
+            _lib.check(self.L.plb_forward(self.handle, ids.data_ptr(), p(lens), B, S, p(hid), p(ph), p(tk), self._stream()),
+                       "plb_forward")
         return hid, ph, tk
+
+    def pooler(self, hidden):
+        """tanh(pooler(hidden[:, 0])) (modeling_albert.py:403), fp32 [B,H]; ``hidden`` fp32 [B,S,H] on the device."""
+        self._ensure_synced()
+        B, S, H = hidden.shape
+        with torch.cuda.device(self.device):
+            out = torch.empty((B, H), dtype=torch.float32, device=self.device)
+            _lib.check(self.L.plb_pooler(self.handle, hidden.data_ptr(), B, S, out.data_ptr(), self._stream()), "plb_pooler")
+        return out
+
+    def loss_fwd(self, masked_ids, labels, lengths, idx_offsets, idx_flat, n_masked, token_ids=None):
+        """Loss of one batch WITHOUT the backward (validate(), train.py:288-304; process_batch under no_grad):
+        plb_loss_fwd — the gradient buffer is not touched. Returns the 1-element device loss tensor."""
+        return self._loss_call(False, masked_ids, labels, lengths, idx_offsets, idx_flat, n_masked, token_ids)
 
     def loss_fwd_bwd(self, masked_ids, labels, lengths, idx_offsets, idx_flat, n_masked, token_ids=None):
         """Loss of one batch + gradients of every trainable parameter into ``self.grads``.
@@ -144,6 +237,11 @@ class HipEngine:
         With ``token_ids`` (int64 [B,S], the 4-tuple Collater's first element) the step is dual-head:
         loss = phoneme loss + token loss, ``self.loss_parts`` holds the two terms and the token head's
         gradients are produced too."""
+        return self._loss_call(True, masked_ids, labels, lengths, idx_offsets, idx_flat, n_masked, token_ids)
+
+    def _loss_call(self, backward, masked_ids, labels, lengths, idx_offsets, idx_flat, n_masked, token_ids):
+        if backward and not self.train_mode:
+            raise RuntimeError("this HipEngine was built with train=False (inference / validation only)")
         self._ensure_synced()
         masked_ids = self._dev_i64(masked_ids)
         labels = self._dev_i64(labels)
@@ -151,22 +249,30 @@ class HipEngine:
         lens = self._dev_i32(lengths)
         offs = self._dev_i32(idx_offsets)
         flat = self._dev_i32(idx_flat)
+        tok = None
         if token_ids is not None:
             if not self.num_tokens:
                 raise ValueError("token_ids given but the engine was built without a token head (num_tokens = 0)")
             tok = self._dev_i64(token_ids)
             if tok.shape != masked_ids.shape:
                 raise ValueError("token_ids must have the shape of the phoneme batch")
-            _lib.check(self.L.plb_loss_fwd_bwd_dual(self.handle, masked_ids.data_ptr(), labels.data_ptr(), tok.data_ptr(),
-                                                    None if lens is None else lens.data_ptr(), offs.data_ptr(),
-                                                    flat.data_ptr() if n_masked else None, int(n_masked), B, S,
-                                                    self._loss.data_ptr(), self._loss_parts.data_ptr(), self._stream()),
-                       "plb_loss_fwd_bwd_dual")
-            return self._loss
-        _lib.check(self.L.plb_loss_fwd_bwd(self.handle, masked_ids.data_ptr(), labels.data_ptr(),
-                                           None if lens is None else lens.data_ptr(), offs.data_ptr(),
-                                           flat.data_ptr() if n_masked else None, int(n_masked), B, S,
-                                           self._loss.data_ptr(), self._stream()), "plb_loss_fwd_bwd")
+        p = lambda t: None if t is None else t.data_ptr()
+        flat_p = flat.data_ptr() if n_masked else None
+        with torch.cuda.device(self.device):
+            if not backward:
+                _lib.check(self.L.plb_loss_fwd(self.handle, masked_ids.data_ptr(), labels.data_ptr(), p(tok), p(lens),
+                                               offs.data_ptr(), flat_p, int(n_masked), B, S, self._loss.data_ptr(),
+                                               self._loss_parts.data_ptr() if tok is not None else None, self._stream()),
+                           "plb_loss_fwd")
+            elif tok is not None:
+                _lib.check(self.L.plb_loss_fwd_bwd_dual(self.handle, masked_ids.data_ptr(), labels.data_ptr(), tok.data_ptr(),
+                                                        p(lens), offs.data_ptr(), flat_p, int(n_masked), B, S,
+                                                        self._loss.data_ptr(), self._loss_parts.data_ptr(), self._stream()),
+                           "plb_loss_fwd_bwd_dual")
+            else:
+                _lib.check(self.L.plb_loss_fwd_bwd(self.handle, masked_ids.data_ptr(), labels.data_ptr(), p(lens),
+                                                   offs.data_ptr(), flat_p, int(n_masked), B, S, self._loss.data_ptr(),
+                                                   self._stream()), "plb_loss_fwd_bwd")
         return self._loss
 
     @property
@@ -182,6 +288,8 @@ class HipEngine:
         return (self.layout["token_predictor.weight"][0], self.total)
 
     def adamw_step(self, step, lr=7e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, grad_scale=1.0):
-        _lib.check(self.L.plb_adamw_step(self.handle, lr, betas[0], betas[1], eps, weight_decay, int(step),
-                                         grad_scale, self._stream()), "plb_adamw_step")
+        self._bind()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.plb_adamw_step(self.handle, lr, betas[0], betas[1], eps, weight_decay, int(step),
+                                             grad_scale, self._stream()), "plb_adamw_step")
         self._synced_version = self.params._version

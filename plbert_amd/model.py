@@ -78,7 +78,11 @@ class AlbertModel(nn.Module):
         self._device = device
         self._seed = seed
         self._engine = None
-        self._build(HipEngine(config, 4, 0, max_batch=self._max_batch, max_seq=self._max_seq, device=device),
+        # An encoder on its own is an inference model (README.md:91: bert(texts, attention_mask=...)): its engine holds
+        # the parameters and, from the first forward on, one layer of activations (< 1 GB at 32 x 512) — no gradient,
+        # moment or per-layer stash. Wrapped by PhonemeOnlyModel / MultiTaskModel its parameters move into the
+        # wrapper's training engine before this one has allocated anything but them.
+        self._build(HipEngine(config, 4, 0, max_batch=self._max_batch, max_seq=self._max_seq, device=device, train=False),
                     reference_init_state_dict(config, 4, 0, seed=seed), prefix="encoder.")
 
     # -- module tree with the reference's parameter names ----------------------------------------------
@@ -129,9 +133,8 @@ class AlbertModel(nn.Module):
             raise ValueError("the HIP path implements the reference's implicit token_type_ids=0 / position_ids=arange")
         lengths = _lengths_from_mask(attention_mask)
         hid, _, _ = self._engine.forward(input_ids, lengths, want_hidden=True, want_phoneme=False)
-        # pooler (modeling_albert.py:403): computed for API completeness, never used by the loss
-        pooled = torch.tanh(torch.nn.functional.linear(hid[:, 0], self.pooler.weight, self.pooler.bias))
-        return BaseModelOutputWithPooling(last_hidden_state=hid, pooler_output=pooled)
+        # pooler (modeling_albert.py:403): computed for API completeness (plb_pooler), never used by the loss
+        return BaseModelOutputWithPooling(last_hidden_state=hid, pooler_output=self._engine.pooler(hid))
 
 
 class _HeadModel(nn.Module):

@@ -73,7 +73,16 @@ class PLBertTrainer:
 
     def __init__(self, cfg, num_phonemes, max_batch=32, max_seq=512, lr=7e-5, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.01, device=None, seed=0, state_dict=None, process_group=None, force_collectives=False,
-                 num_tokens=0):
+                 num_tokens=0, comm="auto", overlap=True):
+        """``comm``: how the gradient exchange of a data-parallel run travels.
+        "rccl"  — the engine's own RCCL communicator behind the C ABI (plb_comm_init / plb_allreduce_grads): the
+                  all-reduce is issued by plb_loss_fwd_bwd itself, piece by piece on the engine's communication
+                  stream while the remaining weight-gradient GEMMs run (``overlap``); torch.distributed only
+                  carries the 128-byte unique id. Needs one GPU per rank.
+        "torch" — ``torch.distributed.all_reduce`` on the flat buffer (dist.GradReducer): gloo in the CPU / shared-GPU
+                  tests, or any backend the caller initialised.
+        "auto"  — "rccl" when the process group spans more than one rank (or ``force_collectives``) and every rank of
+                  this node has a GPU of its own, else "torch"."""
         self.engine = HipEngine(cfg, num_phonemes, num_tokens, max_batch=max_batch, max_seq=max_seq, device=device)
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.step_count = 0
@@ -81,9 +90,21 @@ class PLBertTrainer:
         self.world = self.reducer.world
         sd = state_dict if state_dict is not None else reference_init_state_dict(cfg, num_phonemes, num_tokens, seed=seed)
         self.engine.load_state_dict(sd)
-        if self.reducer.active:  # DDP's start-up broadcast of rank 0's parameters
-            self.reducer.broadcast_(self.engine.params)
-            self.engine.sync_weights()
+        self.comm = "none"
+        if self.reducer.active:
+            if comm == "auto":
+                comm = "rccl" if own_gpu_per_rank() else "torch"
+            if comm == "rccl":
+                uid = exchange_unique_id(HipEngine.comm_unique_id if self.reducer.rank == 0 else None, process_group)
+                self.engine.comm_init(uid, self.reducer.rank, self.world)
+                self.engine.set_grad_overlap(overlap)
+                self.engine.broadcast_params(0)  # DDP's start-up broadcast of rank 0's parameters
+            elif comm == "torch":
+                self.reducer.broadcast_(self.engine.params)
+                self.engine.sync_weights()
+            else:
+                raise ValueError(f"comm must be 'auto', 'rccl' or 'torch', not {comm!r}")
+            self.comm = comm
 
     def stage_batch(self, labels, masked, lengths, masked_indices, validate=True, token_ids=None):
         if validate:
@@ -109,6 +130,9 @@ class PLBertTrainer:
         """Sum the trainable gradient range over ranks (RCCL over xGMI, one collective in the step's stream:
         see dist.GradReducer); the AdamW kernel applies the 1/world factor. A dual-head step also carries
         the token head's gradients."""
+        if self.comm == "rccl":
+            self.engine.allreduce_grads()  # joins the pieces plb_loss_fwd_bwd issued (or reduces now: overlap off)
+            return
         self.reducer.all_reduce_(self.engine.grads[: self.engine.trainable])
         if dual:
             a, b = self.engine.token_range
@@ -125,6 +149,42 @@ class PLBertTrainer:
         self.engine.adamw_step(self.step_count, self.lr, self.betas, self.eps, self.weight_decay,
                                grad_scale=1.0 / self.world)
         return loss
+
+
+def own_gpu_per_rank():
+    """True when every rank launched on this node can have a GPU to itself (RCCL refuses two ranks on one device)."""
+    import os
+    import torch.distributed as dist
+    local_world = os.environ.get("LOCAL_WORLD_SIZE")
+    if local_world is None:  # not under a launcher: assume every rank of the group lives on this node
+        local_world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return torch.cuda.device_count() >= int(local_world)
+
+
+_uid_round = [0]
+
+
+def exchange_unique_id(make, group=None):
+    """Rank 0 of ``group`` creates the RCCL unique id (``make()``), everyone receives its 128 bytes. Over the
+    process group's key-value store when there is one (no device traffic, so torch creates no communicator of its
+    own), else as a broadcast object."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    store = None
+    if group is None:
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:
+            store = None
+    if store is not None:
+        key = f"plbert_rccl_uid_{_uid_round[0]}"
+        _uid_round[0] += 1
+        if rank == 0:
+            store.set(key, make())
+        return bytes(store.get(key))
+    box = [make() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return bytes(box[0])
 
 
 # ---- drop-in forms of the reference's step functions ---------------------------------------------------
@@ -215,6 +275,51 @@ def device_mask_batch(labels, lengths=None, seed=1, step=0, word_pred_prob=0.15,
     return StagedBatch(masked, labels_t, lengths_t, offsets, flat[:n], n, n_tokens)
 
 
+def device_apply_mask(records, device=None, word_separator=None):
+    """Bit-exact masking through the GPU: ``records`` are ``MaskedPhonemeDataset.decisions(i)``
+    dicts — the reference's random draws, made on the host in the reference's order — and plb_apply_mask does the
+    integer work (crop, mask / replace, separator handling, index re-basing, zero padding, length-descending batch
+    order) on the device. Returns (StagedBatch, labels, masked, lengths, token_ids|None): identical to what
+    ``PhonemeOnlyCollater()([ds[i] ...])`` / ``Collater()`` return (tests/test_gpu_apply_mask.py)."""
+    import ctypes as C
+
+    from . import _lib
+    from .data import collate_decisions
+    from .symbols import MASK_ID
+
+    L = _lib.lib()
+    dev = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+    c = collate_decisions(records)
+    B, S = c["B"], c["S"]
+    if B < 1 or S < 1:
+        raise ValueError("device_apply_mask needs at least one non-empty sample")
+    with torch.cuda.device(dev):
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev, non_blocking=True)
+        ids, repl = up(c["ids"]), up(c["repl"])
+        sample_off, word_off = up(c["sample_off"]), up(c["word_off"])
+        word_begin, word_len, action = up(c["word_begin"]), up(c["word_len"]), up(c["action"])
+        crop = up(c["crop_start"])
+        wtok = None if c["word_token"] is None else up(c["word_token"])
+        labels = torch.empty((B, S), dtype=torch.int64, device=dev)
+        masked = torch.empty_like(labels)
+        tokens = torch.empty_like(labels) if wtok is not None else None
+        lens = torch.empty(B, dtype=torch.int32, device=dev)
+        offsets = torch.empty(B + 1, dtype=torch.int32, device=dev)
+        flat = torch.empty(B * S, dtype=torch.int32, device=dev)
+        scratch = torch.empty(B + B * S, dtype=torch.int32, device=dev)
+        p = lambda t: None if t is None else t.data_ptr()
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(L.plb_apply_mask(ids.data_ptr(), sample_off.data_ptr(), word_off.data_ptr(), word_begin.data_ptr(),
+                                    word_len.data_ptr(), action.data_ptr(), repl.data_ptr(), p(wtok),
+                                    int(word_separator if word_separator is not None else 0), crop.data_ptr(), B, S,
+                                    MASK_ID, labels.data_ptr(), masked.data_ptr(), p(tokens), lens.data_ptr(),
+                                    offsets.data_ptr(), flat.data_ptr(), scratch.data_ptr(), stream), "plb_apply_mask")
+        n = int(offsets[B].item())
+    lengths = c["lengths"]
+    lengths_t = None if all(l == S for l in lengths) else lens
+    return StagedBatch(masked, labels, lengths_t, offsets, flat[:n], n, int(sum(lengths)), tokens), labels, masked, lengths, tokens
+
+
 def process_batch(model, batch, criterion=None, accelerator=None):
     """train.py:381-390 — ``batch = (phoneme_labels, masked_phonemes, input_lengths, masked_indices)``.
     ``criterion`` / ``accelerator`` are accepted for signature compatibility: the loss is the
@@ -232,8 +337,9 @@ def process_batch(model, batch, criterion=None, accelerator=None):
         params.append(p)
     if torch.is_grad_enabled():
         return _FusedLoss.apply(engine, names, staged, *params)
-    return engine.loss_fwd_bwd(staged.masked, staged.labels, staged.lengths, staged.offsets, staged.flat,
-                               staged.n_masked, token_ids=staged.token_ids)[0].clone()
+    # validate() (train.py:288-304): forward + loss only; the gradient buffer is left alone
+    return engine.loss_fwd(staged.masked, staged.labels, staged.lengths, staged.offsets, staged.flat,
+                           staged.n_masked, token_ids=staged.token_ids)[0].clone()
 
 
 class AdamW:
@@ -250,7 +356,6 @@ class AdamW:
         self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.step_count = 0
         self.grad_scale = 1.0
-        self._token_stepped = False  # the token head has optimizer state once a dual-head step updated it
         by_id = {id(p): n for n, p in model.named_parameters()}
         self._names = [by_id[id(p)] for p in self.param_list]
 
@@ -271,8 +376,6 @@ class AdamW:
             in_range = off + size <= e.trainable or off >= e.token_range[0]
             if p.grad is not None and in_range and p.grad.data_ptr() != e.grads.data_ptr() + 4 * off:
                 e.grads[off:off + size].view(shp).copy_(p.grad)
-            if p.grad is not None and off >= e.token_range[0]:
-                self._token_stepped = True
         self.step_count += 1
         d = self.defaults
         self.engine.adamw_step(self.step_count, d["lr"], d["betas"], d["eps"], d["weight_decay"], self.grad_scale)
@@ -281,17 +384,25 @@ class AdamW:
         """torch.optim.AdamW layout ({'state': {index: {step, exp_avg, exp_avg_sq}}, 'param_groups': [...]}) with
         parameter indices in ``model.parameters()`` order, so the 'optimizer' entry of a checkpoint
         (train.py:417-421) can be loaded by either implementation. Parameters that never received a
-        gradient (the pooler) have no state, as in torch."""
+        gradient (the pooler; the token head before its first dual-head step) have no state, as in torch; the token
+        head carries its own step count (it may have started later than the encoder)."""
         e = self.engine
         d = self.defaults
         state = {}
-        if self.step_count > 0:
-            for i, n in enumerate(self._names):
-                off, size, shp = e.layout[n]
-                if off + size <= e.trainable or (self._token_stepped and off >= e.token_range[0]):
-                    state[i] = {"step": torch.tensor(float(self.step_count)),
-                                "exp_avg": e.exp_avg[off:off + size].view(shp).clone(),
-                                "exp_avg_sq": e.exp_avg_sq[off:off + size].view(shp).clone()}
+        ta = e.token_range[0]
+        tok_steps = e.token_head_steps
+        for i, n in enumerate(self._names):
+            off, size, shp = e.layout[n]
+            if off + size <= e.trainable:
+                steps = self.step_count
+            elif off >= ta and e.num_tokens:
+                steps = tok_steps
+            else:
+                steps = 0
+            if steps > 0:
+                state[i] = {"step": torch.tensor(float(steps)),
+                            "exp_avg": e.exp_avg[off:off + size].view(shp).clone(),
+                            "exp_avg_sq": e.exp_avg_sq[off:off + size].view(shp).clone()}
         group = {"lr": d["lr"], "betas": tuple(d["betas"]), "eps": d["eps"], "weight_decay": d["weight_decay"],
                  "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
                  "fused": None, "decoupled_weight_decay": True, "params": list(range(len(self.param_list)))}
@@ -299,24 +410,29 @@ class AdamW:
 
     def load_state_dict(self, sd):
         e = self.engine
+        e._bind()
         if "param_groups" in sd:
             g = sd["param_groups"][0]
             for k in ("lr", "betas", "eps", "weight_decay"):
                 if k in g:
                     self.defaults[k] = tuple(g[k]) if k == "betas" else g[k]
-            steps = set()
+            steps, tok_steps = set(), set()
             e.exp_avg.zero_()
             e.exp_avg_sq.zero_()
+            ta = e.token_range[0]
             for i, st in sd["state"].items():
                 off, size, shp = e.layout[self._names[int(i)]]
-                if off + size > e.trainable:
-                    continue
+                is_tok = bool(e.num_tokens) and off >= ta
+                if off + size > e.trainable and not is_tok:
+                    continue  # the pooler never trains
                 e.exp_avg[off:off + size].view(shp).copy_(st["exp_avg"])
                 e.exp_avg_sq[off:off + size].view(shp).copy_(st["exp_avg_sq"])
-                steps.add(int(float(st["step"])))
-            if len(steps) > 1:
-                raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): the fused AdamW keeps one step")
+                (tok_steps if is_tok else steps).add(int(float(st["step"])))
+            if len(steps) > 1 or len(tok_steps) > 1:
+                raise ValueError(f"per-parameter step counts differ ({sorted(steps)} / token head {sorted(tok_steps)}): "
+                                 "the fused AdamW keeps one step for the encoder + phoneme head and one for the token head")
             self.step_count = steps.pop() if steps else 0
+            e.token_head_steps = tok_steps.pop() if tok_steps else 0
             return
         self.step_count = int(sd["step"])  # compact form written by early versions of this class
         e.exp_avg[: e.trainable].copy_(sd["exp_avg"])

@@ -151,3 +151,35 @@ def test_bench_maps_profiler_classes_to_rocprof_kernel_names():
     assert bench._in_class("gemm_tn", "(anonymous namespace)::gemm_tn_big_kernel(PlbGemmTN)")
     assert not bench._in_class("gemm_nt", "(anonymous namespace)::gemm_tn_big_kernel(PlbGemmTN)")
     assert bench._in_class("attn_bwd_dkv", "(anonymous namespace)::attn_bwd_dkv_kernel(PlbAttn)")
+
+
+def test_bench_parent_spawns_ranks_without_touching_the_gpu(monkeypatch, capsys):
+    """`python bench.py --gpus N` as typed: the parent must start N ranks through torch.distributed.run on
+    127.0.0.1 BEFORE importing torch / making any GPU call, and relay rank 0's single JSON line."""
+    import importlib
+    import subprocess
+    import sys as _sys
+    import types
+
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=0, stdout='noise\n{"metric": "phoneme-tokens/sec", "n_gpus": 4}\n')
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(_sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    monkeypatch.delenv("RANK", raising=False)
+    torch_loaded_before = "torch.cuda" in _sys.modules and _sys.modules["torch"].cuda.is_initialized()
+    with pytest.raises(SystemExit) as ex:
+        bench.main()
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert capsys.readouterr().out.strip() == '{"metric": "phoneme-tokens/sec", "n_gpus": 4}'
+    if "torch" in _sys.modules:
+        assert _sys.modules["torch"].cuda.is_initialized() == torch_loaded_before

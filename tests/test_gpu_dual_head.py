@@ -155,3 +155,56 @@ def test_dual_64k_vocabulary_properties():
     for _ in range(3):
         l1 = float(tr.step(batch).item())
     assert l1 < l0                                                           # both heads learn
+
+
+def test_dual_head_optimizer_state_round_trips_and_keeps_its_own_step():
+    """AdamW.state_dict()/load_state_dict() must carry the token head's moments and step. A model that
+    trains phoneme-only first and dual-head later has DIFFERENT step counts for the two ranges (torch keeps one per
+    parameter); save -> load into a fresh model -> the next dual step is bit-identical to the uninterrupted run."""
+    from plbert_amd.train import AdamW, process_batch
+    g = load_golden("small_h128_dualloss")
+    ocfg, pcfg, sd = golden_cfg(g)
+    B, S = g["labels"].shape
+    NT = int(g["num_tokens"])
+    idx = [list(map(int, x)) for x in g["index"]]
+    lens = [int(x) for x in g["lengths"]]
+    b3 = (torch.from_numpy(g["labels"]), torch.from_numpy(g["masked"]), lens, idx)
+    b4 = (torch.from_numpy(g["token_ids"]),) + b3
+
+    def make():
+        m = plbert_amd.MultiTaskModel(plbert_amd.AlbertModel(pcfg, max_batch=B, max_seq=S), 188, NT, pcfg.hidden_size)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        return m, AdamW(m.parameters(), lr=1e-3, model=m)
+
+    def step(m, opt, batch):
+        loss = process_batch(m, batch)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return float(loss)
+
+    m, opt = make()
+    step(m, opt, b3); step(m, opt, b3)            # two phoneme-only steps: the token head has no state yet
+    st = opt.state_dict()
+    names = [n for n, _ in m.named_parameters()]
+    tok_idx = [i for i, n in enumerate(names) if n.startswith("token_predictor")]
+    assert all(i not in st["state"] for i in tok_idx)
+    step(m, opt, b4)                              # first dual step: token head step 1, encoder step 3
+    st = opt.state_dict()
+    assert all(float(st["state"][i]["step"]) == 1.0 for i in tok_idx)
+    assert float(st["state"][names.index("phoneme_predictor.weight")]["step"]) == 3.0
+    # torch's own AdamW accepts the saved state (train.py:417-421 'optimizer' entry)
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in m.parameters()]
+    torch.optim.AdamW(ref_params, lr=1e-3).load_state_dict(st)
+    net = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    l_next = step(m, opt, b4)                     # uninterrupted run: step 4 / 2
+    # resume in a fresh model
+    m2, opt2 = make()
+    m2.load_state_dict(net, strict=False)
+    opt2.load_state_dict(st)
+    assert opt2.step_count == 3 and m2.engine.token_head_steps == 1
+    l_res = step(m2, opt2, b4)
+    torch.cuda.synchronize()
+    assert l_res == l_next
+    for (n, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), n

@@ -176,7 +176,7 @@ def test_layernorm_fwd_bwd(T, H):
     dy = randbf(T + 3, H, seed=12)
     dx = torch.full((T + 3, H), 3.0, dtype=torch.bfloat16, device=DEV)
     nb = 64
-    part = torch.zeros((nb, 2 * H), device=DEV)
+    part = torch.zeros((nb, 3 * H), device=DEV)
     p.dy, p.lddy, p.dx, p.lddx, p.partials, p.nblocks = dy.data_ptr(), H, dx.data_ptr(), H, part.data_ptr(), nb
     assert L.plb_launch_ln_bwd(C.byref(p), stream()) == 0
     torch.cuda.synchronize()
@@ -187,7 +187,9 @@ def test_layernorm_fwd_bwd(T, H):
     assert rel_l2(dx[:T].float(), xr2.grad) < 5e-3
     assert (dx[T:] == 0).all()
     assert rel_l2(part.sum(0)[:H], gw.grad) < 1e-4
-    assert rel_l2(part.sum(0)[H:], gb.grad) < 1e-4
+    assert rel_l2(part.sum(0)[H:2 * H], gb.grad) < 1e-4
+    # third block: column sums of dx as stored (the bias gradient of the Linear in front of the LayerNorm)
+    assert rel_l2(part.sum(0)[2 * H:], dx[:T].float().sum(0)) < 1e-5
 
 
 def test_colsum():
