@@ -146,9 +146,11 @@ int plb_loss_fwd_bwd_dual(PlbEngine* e, const int64_t* masked_ids, const int64_t
 
 /* Stands in for torch.optim.AdamW.step (train.py:272,357): decoupled weight decay on every
  * trainable parameter, bias-corrected moments; `step` counts from 1; gradients are multiplied by
- * grad_scale first (1/world_size after a sum all-reduce). Also refreshes the bf16 copies. */
-int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
-                   float grad_scale, void* stream);
+ * grad_scale first (1/world_size after a sum all-reduce). Also refreshes the bf16 copies. Hyper-parameters are
+ * doubles, as torch holds them: the update's scalars (1 - beta2, lr / bias_correction1, ...) are formed in double and
+ * rounded to fp32 once, which is what makes the result agree with torch.optim.AdamW to the last bits. */
+int plb_adamw_step(PlbEngine* e, double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step,
+                   double grad_scale, void* stream);
 
 /* The token head (trained by dual-head steps only) keeps its own AdamW step count, as torch keeps one per parameter
  * (train.py:417-421 saves it in 'optimizer'). Read / restore it around checkpoints. */

@@ -138,7 +138,7 @@ def lib():
         L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     except OSError as ex:
         raise HipLibraryMissing(f"cannot load {LIB_PATH}: {ex}") from ex
-    vp, i32, i64p, f32 = C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_float
+    vp, i32, i64p, f32, f64 = C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_float, C.c_double
     L.plb_last_error.restype = C.c_char_p
     L.plb_last_error.argtypes = []
     L.plb_create.restype = C.c_int
@@ -184,7 +184,7 @@ def lib():
     L.plb_apply_mask.restype = C.c_int
     L.plb_apply_mask.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int64, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.plb_adamw_step.restype = C.c_int
-    L.plb_adamw_step.argtypes = [vp, f32, f32, f32, f32, f32, i32, f32, vp]
+    L.plb_adamw_step.argtypes = [vp, f64, f64, f64, f64, f64, i32, f64, vp]
     L.plb_mask_batch.restype = C.c_int
     L.plb_mask_batch.argtypes = [vp, vp, i32, i32, C.c_uint64, C.c_uint32, f32, f32, f32, i32, i32, vp, vp, vp, vp, vp]
     L.plb_profile_enable.restype = None

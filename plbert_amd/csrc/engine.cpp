@@ -1044,8 +1044,8 @@ extern "C" int plb_mask_batch(const int64_t* labels, const int32_t* lengths, int
   return 0;
 }
 
-extern "C" int plb_adamw_step(PlbEngine* e, float lr, float beta1, float beta2, float eps, float weight_decay,
-                              int32_t step, float grad_scale, void* stream) {
+extern "C" int plb_adamw_step(PlbEngine* e, double lr, double beta1, double beta2, double eps, double weight_decay,
+                              int32_t step, double grad_scale, void* stream) {
   if (!e || !e->ws || !e->grads || !e->m || !e->v) return fail("plb_adamw_step: optimizer buffers not bound");
   if (e->infer) return fail("plb_adamw_step: inference-only engine");
   if (step < 1) return fail("plb_adamw_step: step counts from 1");

@@ -164,8 +164,8 @@ typedef struct {
 int plb_launch_apply_mask(const PlbApplyMask* p, hipStream_t stream);
 
 // AdamW (torch.optim.AdamW semantics) over a flat range; also refreshes the bf16 compute copy.
-int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, float lr, float beta1,
-                     float beta2, float eps, float wd, int step, float grad_scale, hipStream_t stream);
+int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, double lr, double beta1,
+                     double beta2, double eps, double wd, int step, double grad_scale, hipStream_t stream);
 int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream);
 // dst[c, r] = bf16(src[r, c]) for r<R, c<C ; dst has ldd >= R columns (zero fill is the caller's job)
 int plb_launch_transpose_cast(const float* src, int R, int C, bf16_t* dst, int ldd, hipStream_t stream);

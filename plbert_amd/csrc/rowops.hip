@@ -512,22 +512,24 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* x, int n, fl
 }
 
 // -------------------------------------------------------------------------------- optimizer (A12)
-// torch.optim.AdamW single-tensor semantics: p *= 1 - lr*wd; m,v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+// torch.optim.AdamW semantics, operation for operation (torch/optim/adamw.py -> adam.py, the default foreach form):
+//   p *= 1 - lr*wd;  m = lerp(m, g, 1-b1);  v = b2*v + (1-b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// The scalars are formed on the host in DOUBLE and rounded once, as torch forms them in Python floats: 1.0f - 0.999f
+// is 0.99998713e-3, not 1e-3f — a 1.3e-5 relative error in every second moment (tests/test_gpu_adamw_kernel.py).
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* pb, size_t n,
-                                                    float lr, float b1, float b2, float eps, float wd, float bc1,
-                                                    float rsqrt_bc2, float gscale) {
+                                                    float decay, float omb1, float b2, float omb2, float eps, float step,
+                                                    float bc2_sqrt, float gscale) {
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;  // n is a multiple of 4 (checked by the launcher)
   float4 P = *(const float4*)(p + i), G = *(const float4*)(g + i), M = *(const float4*)(m + i), V = *(const float4*)(v + i);
   float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
-  const float step = lr / bc1, decay = 1.0f - lr * wd;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const float gj = gg[j] * gscale;
     pp[j] *= decay;
-    mm[j] = b1 * mm[j] + (1.0f - b1) * gj;
-    vv[j] = b2 * vv[j] + (1.0f - b2) * gj * gj;
-    const float denom = sqrtf(vv[j]) * rsqrt_bc2 + eps;
+    mm[j] = mm[j] + omb1 * (gj - mm[j]);
+    vv[j] = b2 * vv[j] + omb2 * (gj * gj);
+    const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
     pp[j] -= step * (mm[j] / denom);
   }
   *(float4*)(p + i) = make_float4(pp[0], pp[1], pp[2], pp[3]);
@@ -707,15 +709,16 @@ extern "C" int plb_launch_sum_rows(const float* x, int n, float* out, hipStream_
   hipLaunchKernelGGL(sum_rows_kernel, dim3(1), dim3(256), 0, stream, x, n, out);
   return LAUNCH_OK();
 }
-extern "C" int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, float lr,
-                                float beta1, float beta2, float eps, float wd, int step, float grad_scale,
+extern "C" int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, double lr,
+                                double beta1, double beta2, double eps, double wd, int step, double grad_scale,
                                 hipStream_t stream) {
   if (n % 4 || step < 1) return 1;
   if (!n) return 0;
   ProfScope ps(PLB_K_ADAMW, stream, 0, (double)n * 30.0);  // p,m,v read+write, g read, bf16 copy
-  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, p_bf16, n, lr,
-                     beta1, beta2, eps, wd, (float)bc1, (float)(1.0 / sqrt(bc2)), grad_scale);
+  const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, p_bf16, n,
+                     (float)(1.0 - lr * wd), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                     (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream) {

@@ -63,7 +63,7 @@ class HipEngine:
         # gradients, AdamW moments and the workspace are allocated by the first call that computes (_bind): a model
         # that is only constructed, or whose parameters move into another engine (model.py: _adopt), holds its
         # parameters and nothing else
-        self.grads = self.exp_avg = self.exp_avg_sq = self.workspace = None
+        self._grads = self._exp_avg = self._exp_avg_sq = self.workspace = None
         self.ws_bytes = int(self.L.plb_workspace_bytes(h))
         self._bound = False
         self._synced_version = -1
@@ -75,17 +75,36 @@ class HipEngine:
         with torch.cuda.device(self.device):
             z = lambda n: torch.zeros(n, dtype=torch.float32, device=self.device)
             if self.train_mode:
-                self.grads, self.exp_avg, self.exp_avg_sq = z(self.total), z(self.total), z(self.total)
+                self._grads, self._exp_avg, self._exp_avg_sq = z(self.total), z(self.total), z(self.total)
             self.workspace = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.device)
             p = lambda t: None if t is None else t.data_ptr()
             # plb_bind creates the engine's side stream and events on the current device
-            _lib.check(self.L.plb_bind(self.handle, self.params.data_ptr(), p(self.grads), p(self.exp_avg),
-                                       p(self.exp_avg_sq), self.workspace.data_ptr(), self.ws_bytes), "plb_bind")
+            _lib.check(self.L.plb_bind(self.handle, self.params.data_ptr(), p(self._grads), p(self._exp_avg),
+                                       p(self._exp_avg_sq), self.workspace.data_ptr(), self.ws_bytes), "plb_bind")
         self._bound = True
+
+    # flat fp32 gradient / AdamW-moment buffers (None on an inference engine); first access allocates
+    @property
+    def grads(self):
+        if self.train_mode:
+            self._bind()
+        return self._grads
+
+    @property
+    def exp_avg(self):
+        if self.train_mode:
+            self._bind()
+        return self._exp_avg
+
+    @property
+    def exp_avg_sq(self):
+        if self.train_mode:
+            self._bind()
+        return self._exp_avg_sq
 
     def device_bytes(self):
         """Bytes of device memory this engine holds."""
-        ts = [self.params, self.grads, self.exp_avg, self.exp_avg_sq, self.workspace]
+        ts = [self.params, self._grads, self._exp_avg, self._exp_avg_sq, self.workspace]
         return sum(t.numel() * t.element_size() for t in ts if t is not None)
 
     def __del__(self):
