@@ -159,7 +159,16 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(PlbEmbed p, int P) {
 // as in the GEMMs and the attention kernels that produce / consume them (worth 0.05 ms per step, measured).
 // A wave handles LN_R rows per iteration with all their loads issued before the first reduction:
 // the kernels are pure HBM streams and one row per wave (3 x 8 B per lane) left them latency-bound.
-constexpr int LN_R = 2;
+#ifndef LN_R_ROWS
+#define LN_R_ROWS 2
+#endif
+constexpr int LN_R = LN_R_ROWS;
+#ifndef LN_WIDE
+#define LN_WIDE 1   // 16-byte kernels for H = 768 / 1024 (0: the 8-byte kernels for every width)
+#endif
+#ifndef LNW_FWD_BLOCKS
+#define LNW_FWD_BLOCKS 2048
+#endif
 
 template <int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(PlbLayerNorm p) {
@@ -300,6 +309,223 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * H; i += 256) {  // partials[block][dgamma | dbeta | colsum(dx)]
+    const int which = i / H, col = i % H;
+    p.partials[(size_t)blockIdx.x * 3 * H + i] =
+        red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+  }
+}
+
+// ---- 16-byte form for the model widths (H = 768: 96 chunks of 8 bf16 per row, H = 1024: 128) -------------------------
+// A wave takes RW consecutive rows as ONE run of RW*CPR 16-byte chunks, NL = RW*CPR/64 loads per lane (lane l, load i:
+// chunk l + 64 i -> row (l + 64 i) / CPR, columns ((l + 64 i) % CPR) * 8 ...): full 1-KiB wave loads and stores, half
+// the memory instructions of the 8-byte form, and LNW_GROUPS row groups in flight per wave before the first
+// reduction. H = 768: RW = 2, NL = 3 (load 1 straddles the two rows); H = 1024: RW = 1, NL = 2.
+#ifndef LNW_GROUPS
+#define LNW_GROUPS 2
+#endif
+template <int CPR> struct LnWide {
+  static constexpr int RW = (CPR == 96) ? 2 : 1;
+  static constexpr int NL = RW * CPR / 64;
+  static_assert(RW * CPR % 64 == 0, "row group must fill whole wave loads");
+};
+DEVI void unpack8(const uint4& u, float (&f)[8]) {
+  f[0] = bf_lo(u.x); f[1] = bf_hi(u.x); f[2] = bf_lo(u.y); f[3] = bf_hi(u.y);
+  f[4] = bf_lo(u.z); f[5] = bf_hi(u.z); f[6] = bf_lo(u.w); f[7] = bf_hi(u.w);
+}
+DEVI uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+
+template <int CPR>
+__global__ __launch_bounds__(256) void ln_fwd_wide_kernel(PlbLayerNorm p) {
+  constexpr int RW = LnWide<CPR>::RW, NL = LnWide<CPR>::NL, G = LNW_GROUPS, H = CPR * 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invH = 1.0f / (float)H;
+  int lrow[NL], lcol[NL];
+  float gm[NL][8], bt[NL][8];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int c = lane + 64 * i;
+    lrow[i] = c / CPR; lcol[i] = (c % CPR) * 8;
+    const float4 g0 = *(const float4*)(p.gamma + lcol[i]), g1 = *(const float4*)(p.gamma + lcol[i] + 4);
+    const float4 b0 = *(const float4*)(p.beta + lcol[i]), b1 = *(const float4*)(p.beta + lcol[i] + 4);
+    gm[i][0] = g0.x; gm[i][1] = g0.y; gm[i][2] = g0.z; gm[i][3] = g0.w; gm[i][4] = g1.x; gm[i][5] = g1.y; gm[i][6] = g1.z; gm[i][7] = g1.w;
+    bt[i][0] = b0.x; bt[i][1] = b0.y; bt[i][2] = b0.z; bt[i][3] = b0.w; bt[i][4] = b1.x; bt[i][5] = b1.y; bt[i][6] = b1.z; bt[i][7] = b1.w;
+  }
+  const int step = gridDim.x * 4 * RW * G;
+  for (int t0 = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * RW * G; t0 < p.T; t0 += step) {
+    uint4 u[G][NL];
+#pragma unroll
+    for (int gI = 0; gI < G; ++gI)
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        int t = t0 + gI * RW + lrow[i];
+        t = t < p.T ? t : p.T - 1;
+        u[gI][i] = *(const uint4*)(p.x + (size_t)t * p.ldx + lcol[i]);
+      }
+#pragma unroll
+    for (int gI = 0; gI < G; ++gI) {
+      float x[NL][8], rs[RW], mean[RW], rstd[RW];
+#pragma unroll
+      for (int r = 0; r < RW; ++r) rs[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        unpack8(u[gI][i], x[i]);
+        const float s = ((x[i][0] + x[i][1]) + (x[i][2] + x[i][3])) + ((x[i][4] + x[i][5]) + (x[i][6] + x[i][7]));
+#pragma unroll
+        for (int r = 0; r < RW; ++r) rs[r] += (lrow[i] == r) ? s : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < RW; ++r) { mean[r] = wave_sum(rs[r]) * invH; rs[r] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        float mu = mean[0];
+#pragma unroll
+        for (int r = 1; r < RW; ++r) mu = (lrow[i] == r) ? mean[r] : mu;
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[i][j] -= mu; v += x[i][j] * x[i][j]; }
+#pragma unroll
+        for (int r = 0; r < RW; ++r) rs[r] += (lrow[i] == r) ? v : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < RW; ++r) rstd[r] = rsqrtf(wave_sum(rs[r]) * invH + p.eps);
+#pragma unroll
+      for (int r = 0; r < RW; ++r) {
+        const int t = t0 + gI * RW + r;
+        if (lane == 0 && p.mean && t < p.T) { p.mean[t] = mean[r]; p.rstd[t] = rstd[r]; }
+      }
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        float rsd = rstd[0];
+#pragma unroll
+        for (int r = 1; r < RW; ++r) rsd = (lrow[i] == r) ? rstd[r] : rsd;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = x[i][j] * rsd * gm[i][j] + bt[i][j];
+        const int t = t0 + gI * RW + lrow[i];
+        if (t < p.T) *(uint4*)(p.y + (size_t)t * p.ldy + lcol[i]) = pack8(o);
+      }
+    }
+  }
+}
+
+template <int CPR>
+__global__ __launch_bounds__(256) void ln_bwd_wide_kernel(PlbLayerNorm p) {
+  constexpr int RW = LnWide<CPR>::RW, NL = LnWide<CPR>::NL, H = CPR * 8;
+  __shared__ float red[4][3][H];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invH = 1.0f / (float)H;
+  int lrow[NL], lcol[NL];
+  float gm[NL][8], dg[NL][8], db[NL][8], dxs[NL][8];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    const int c = lane + 64 * i;
+    lrow[i] = c / CPR; lcol[i] = (c % CPR) * 8;
+    const float4 g0 = *(const float4*)(p.gamma + lcol[i]), g1 = *(const float4*)(p.gamma + lcol[i] + 4);
+    gm[i][0] = g0.x; gm[i][1] = g0.y; gm[i][2] = g0.z; gm[i][3] = g0.w; gm[i][4] = g1.x; gm[i][5] = g1.y; gm[i][6] = g1.z; gm[i][7] = g1.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dg[i][j] = db[i][j] = dxs[i][j] = 0.f;
+  }
+  const int step = gridDim.x * 4 * RW;
+  int t0 = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * RW;
+  // one row group ahead: the loads of group k+1 are in flight while group k is reduced and stored
+  uint4 nx[NL], nd[NL];
+  float nmean[NL], nrstd[NL];
+#define LNW_LOAD(tb)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < NL; ++i) {                                            \
+    int t_ = (tb) + lrow[i];                                                                  \
+    t_ = t_ < p.T ? t_ : p.T - 1;                                                             \
+    nx[i] = *(const uint4*)(p.x + (size_t)t_ * p.ldx + lcol[i]);                              \
+    nd[i] = *(const uint4*)(p.dy + (size_t)t_ * p.lddy + lcol[i]);                            \
+    nmean[i] = p.mean[t_]; nrstd[i] = p.rstd[t_];                                             \
+  }
+  if (t0 < p.T) { LNW_LOAD(t0); }
+  for (; t0 < p.T; t0 += step) {
+    uint4 ux[NL], ud[NL];
+    float mean[NL], rstd[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) { ux[i] = nx[i]; ud[i] = nd[i]; mean[i] = nmean[i]; rstd[i] = nrstd[i]; }
+    if (t0 + step < p.T) { LNW_LOAD(t0 + step); }
+    float xh[NL][8], dxh[NL][8], s1[RW], s2[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) s1[r] = s2[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float xv[8], dyv[8];
+      unpack8(ux[i], xv);
+      unpack8(ud[i], dyv);
+      const bool live = t0 + lrow[i] < p.T;
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = live ? dyv[j] : 0.f;
+        xh[i][j] = (xv[j] - mean[i]) * rstd[i];
+        dxh[i][j] = d * gm[i][j];
+        a1 += dxh[i][j]; a2 += dxh[i][j] * xh[i][j];
+        dg[i][j] += d * xh[i][j]; db[i][j] += d;
+      }
+#pragma unroll
+      for (int r = 0; r < RW; ++r) { s1[r] += (lrow[i] == r) ? a1 : 0.f; s2[r] += (lrow[i] == r) ? a2 : 0.f; }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) { s1[r] = wave_sum(s1[r]) * invH; s2[r] = wave_sum(s2[r]) * invH; }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      float m1 = s1[0], m2 = s2[0];
+#pragma unroll
+      for (int r = 1; r < RW; ++r) { m1 = (lrow[i] == r) ? s1[r] : m1; m2 = (lrow[i] == r) ? s2[r] : m2; }
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = rstd[i] * (dxh[i][j] - m1 - xh[i][j] * m2);
+      const uint4 pk = pack8(o);
+      if (t0 + lrow[i] < p.T) {
+        *(uint4*)(p.dx + (size_t)(t0 + lrow[i]) * p.lddx + lcol[i]) = pk;
+        float q[8];
+        unpack8(pk, q);  // column sums of dx as stored
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dxs[i][j] += q[j];
+      }
+    }
+  }
+#undef LNW_LOAD
+  // padding rows of the token dimension: keep them zero so they add nothing to the batched dW GEMMs
+  for (int t = p.T + blockIdx.x * 4 + wave; t < p.Tzero; t += gridDim.x * 4)
+    for (int c = lane; c < CPR; c += 64) *(uint4*)(p.dx + (size_t)t * p.lddx + c * 8) = make_uint4(0, 0, 0, 0);
+  // per-block partials: loads i and i' of one lane set can hold the same columns (H = 768: load 1 wraps), so the NL
+  // slots are folded into the wave's LDS row one after the other
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float* r0 = &red[wave][0][lcol[i] + j];
+      if (i == 0 || (CPR == 128)) {  // first touch of these columns by this wave (H = 1024: the two loads are disjoint)
+        r0[0] = dg[i][j]; r0[H] = db[i][j]; r0[2 * H] = dxs[i][j];
+      }
+    }
+    if (CPR != 128 && i + 1 < NL) __builtin_amdgcn_wave_barrier();
+  }
+  if (CPR != 128) {
+    // H = 768: load 0 covered columns [0,512); load 1 lanes 0-31 cover [512,768) (first touch), lanes 32-63 [0,256)
+    // (second touch); load 2 covers [256,768) (second touch)
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float* r1 = &red[wave][0][lcol[1] + j];
+      if (lane < 32) { r1[0] = dg[1][j]; r1[H] = db[1][j]; r1[2 * H] = dxs[1][j]; }
+      else { r1[0] += dg[1][j]; r1[H] += db[1][j]; r1[2 * H] += dxs[1][j]; }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float* r2 = &red[wave][0][lcol[2] + j];
+      r2[0] += dg[2][j]; r2[H] += db[2][j]; r2[2 * H] += dxs[2][j];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * H; i += 256) {
     const int which = i / H, col = i % H;
     p.partials[(size_t)blockIdx.x * 3 * H + i] =
         red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
@@ -613,6 +839,13 @@ extern "C" int plb_launch_ln_fwd(const PlbLayerNorm* p, hipStream_t stream) {
   if (p->H % 4 || p->H > 1024 || p->T <= 0) return 1;
   int blocks = (p->T + 4 * LN_R - 1) / (4 * LN_R); if (blocks > 4096) blocks = 4096;
   ProfScope ps(PLB_K_LN_FWD, stream, 0, (double)p->T * (4.0 * p->H + 8));
+  if (LN_WIDE && (p->H == 768 || p->H == 1024) && p->ldx % 8 == 0 && p->ldy % 8 == 0) {
+    const int rows_per_block = 4 * (p->H == 768 ? 2 : 1) * LNW_GROUPS;
+    int wb = (p->T + rows_per_block - 1) / rows_per_block; if (wb > LNW_FWD_BLOCKS) wb = LNW_FWD_BLOCKS;
+    if (p->H == 768) hipLaunchKernelGGL((ln_fwd_wide_kernel<96>), dim3(wb), dim3(256), 0, stream, *p);
+    else hipLaunchKernelGGL((ln_fwd_wide_kernel<128>), dim3(wb), dim3(256), 0, stream, *p);
+    return LAUNCH_OK();
+  }
   const int nch = (p->H + 255) / 256;
   switch (nch) {
     case 1: hipLaunchKernelGGL((ln_fwd_kernel<1>), dim3(blocks), dim3(256), 0, stream, *p); break;
@@ -625,6 +858,11 @@ extern "C" int plb_launch_ln_fwd(const PlbLayerNorm* p, hipStream_t stream) {
 extern "C" int plb_launch_ln_bwd(const PlbLayerNorm* p, hipStream_t stream) {
   if (p->H % 4 || p->H > 1024 || p->T <= 0 || p->nblocks <= 0) return 1;
   ProfScope ps(PLB_K_LN_BWD, stream, 0, (double)p->T * (6.0 * p->H + 8));
+  if (LN_WIDE && (p->H == 768 || p->H == 1024) && p->ldx % 8 == 0 && p->lddy % 8 == 0 && p->lddx % 8 == 0) {
+    if (p->H == 768) hipLaunchKernelGGL((ln_bwd_wide_kernel<96>), dim3(p->nblocks), dim3(256), 0, stream, *p);
+    else hipLaunchKernelGGL((ln_bwd_wide_kernel<128>), dim3(p->nblocks), dim3(256), 0, stream, *p);
+    return LAUNCH_OK();
+  }
   const int nch = (p->H + 255) / 256;
   switch (nch) {
     case 1: hipLaunchKernelGGL((ln_bwd_kernel<1>), dim3(p->nblocks), dim3(256), 0, stream, *p); break;

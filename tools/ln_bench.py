@@ -20,7 +20,7 @@ def bench(L, T, H, iters=50):
     g, b = torch.randn(H, device=dev), torch.randn(H, device=dev)
     mean, rstd = torch.empty(T, device=dev), torch.empty(T, device=dev)
     nb = 1024
-    part = torch.empty(nb, 2 * H, device=dev)
+    part = torch.empty(nb, 3 * H, device=dev)
     p = _lib.PlbLayerNorm()
     p.x, p.ldx, p.gamma, p.beta, p.eps = x.data_ptr(), H, g.data_ptr(), b.data_ptr(), 1e-12
     p.y, p.ldy, p.mean, p.rstd, p.T, p.H, p.Tzero = y.data_ptr(), H, mean.data_ptr(), rstd.data_ptr(), T, H, T
