@@ -66,6 +66,9 @@ def parse():
                     help="piecewise all-reduce inside the backward (on) or one collective after it (off); auto times "
                          "both during warm-up and keeps the faster")
     ap.add_argument("--no-staged", action="store_true", help="skip the per-step-staging re-run")
+    ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8 = BASELINE configs[4], a separately reported workload: the QKV / FFN GEMMs (forward and FFN "
+                         "dX) on e4m3 / e5m2 operands through the block-scaled MFMA, everything else as in bf16")
     return ap.parse_args()
 
 
@@ -309,6 +312,9 @@ def main():
                             device=f"cuda:{dev_index}", seed=0, force_collectives=args.force_dist,
                             num_tokens=args.num_tokens, comm=comm_mode, overlap=args.overlap != "off")
     eng = trainer.engine
+    if args.dtype == "fp8":
+        eng.set_fp8(True)
+        model_desc += ", fp8 (e4m3 weights/activations, e5m2 gradients) QKV + FFN GEMMs"
     labels, masked, lengths, idx = plbert_amd.synthetic_batch(B, S, seed=1234 + rank)
     token_ids = None
     if args.num_tokens:
@@ -470,7 +476,8 @@ def main():
                                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])
                                          if k in MEMORY_BOUND and v["ms"] > 0 and v["bytes"] > 0]}
 
-    if roofline is not None and world == 1 and not dist.is_initialized() and not args.no_traffic and not args.num_tokens:
+    if roofline is not None and world == 1 and not dist.is_initialized() and not args.no_traffic and not args.num_tokens \
+            and args.dtype == "bf16":
         t = pmc_traffic(roofline["kernel"])
         if t is not None:
             roofline["traffic"] = t["bytes"]
@@ -489,7 +496,7 @@ def main():
         out = {
             "metric": "phoneme-tokens/sec", "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"PL-BERT {'dual-head (phoneme + token loss)' if args.num_tokens else 'masked-phoneme'} "
                                    f"training step (fwd+loss+bwd+allreduce+AdamW), ALBERT "
                                    f"{model_desc}, seq_len {S}, batch {B} per GPU",

@@ -152,6 +152,16 @@ int plb_loss_fwd_bwd_dual(PlbEngine* e, const int64_t* masked_ids, const int64_t
 int plb_adamw_step(PlbEngine* e, double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step,
                    double grad_scale, void* stream);
 
+/* fp8 mode (BASELINE.json configs[4]): the QKV and the two FFN GEMMs of the forward, and the two FFN dX GEMMs of the
+ * backward, run on OCP fp8 operands with fp32 accumulation — e4m3 weights and activations, e5m2 gradients — through the
+ * block-scaled MFMA with unit block scales (twice the bf16 MFMA rate); attention, the dense projection, every weight
+ * gradient, LayerNorm, the loss and the optimizer stay bf16 / fp32. Per-tensor delayed scaling: a tensor is quantised
+ * with 448 (57344) / the maximum it showed in the previous call; the first call after switching the mode on runs in
+ * bf16 and only records the maxima. hidden_size 768 or 1024; calls whose GEMM shapes have no pipeline-tile form run
+ * in bf16. The reference has no fp8 path: parity is against this library's own bf16 path (tests/test_gpu_fp8.py). */
+int plb_set_fp8(PlbEngine* e, int32_t on, void* stream);
+int plb_fp8_state(const PlbEngine* e, int32_t* enabled, int32_t* calibrated);
+
 /* The token head (trained by dual-head steps only) keeps its own AdamW step count, as torch keeps one per parameter
  * (train.py:417-421 saves it in 'optimizer'). Read / restore it around checkpoints. */
 int32_t plb_token_head_steps(const PlbEngine* e);

@@ -53,7 +53,7 @@ PLB_NPARAM = len(PLB_PARAM_NAMES)
 PUBLIC_SYMBOLS = [
     "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
     "plb_sync_weights", "plb_forward", "plb_pooler", "plb_loss_fwd_bwd", "plb_loss_fwd", "plb_loss_fwd_bwd_dual", "plb_adamw_step",
-    "plb_token_head_steps", "plb_set_token_head_steps", "plb_comm_unique_id", "plb_comm_init", "plb_comm_destroy",
+    "plb_set_fp8", "plb_fp8_state", "plb_token_head_steps", "plb_set_token_head_steps", "plb_comm_unique_id", "plb_comm_init", "plb_comm_destroy",
     "plb_comm_info", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
     "plb_mask_batch", "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
 ]
@@ -79,6 +79,8 @@ class PlbGemmNT(C.Structure):
         ("colpart", C.c_void_p),
         ("ce_cols", C.c_int), ("ce_tgt", C.c_void_p), ("ce_pmax", C.c_void_p), ("ce_psum", C.c_void_p),
         ("ce_tlogit", C.c_void_p), ("ce_lse", C.c_void_p), ("ce_w", C.c_void_p),
+        ("deq_a", C.c_void_p), ("deq_b", C.c_void_p), ("C8", C.c_void_p), ("ldc8", C.c_int), ("q_scale", C.c_void_p),
+        ("q_amax", C.c_void_p), ("c8_bf8", C.c_int),
     ]
 
 
@@ -96,6 +98,7 @@ class PlbAttn(C.Structure):
         ("B", C.c_int), ("S", C.c_int), ("NH", C.c_int), ("H", C.c_int), ("scale", C.c_float),
         ("ctx", C.c_void_p), ("ldctx", C.c_int), ("lse", C.c_void_p),
         ("dctx", C.c_void_p), ("lddctx", C.c_int), ("delta", C.c_void_p), ("dqkv", C.c_void_p), ("lddqkv", C.c_int),
+        ("colpart", C.c_void_p),
     ]
 
 
@@ -115,6 +118,7 @@ class PlbLayerNorm(C.Structure):
         ("T", C.c_int), ("H", C.c_int), ("Tzero", C.c_int),
         ("dy", C.c_void_p), ("lddy", C.c_int), ("dx", C.c_void_p), ("lddx", C.c_int),
         ("partials", C.c_void_p), ("nblocks", C.c_int),
+        ("out8", C.c_void_p), ("ld8", C.c_int), ("q_scale", C.c_void_p), ("q_amax", C.c_void_p),
     ]
 
 
@@ -163,6 +167,10 @@ def lib():
     L.plb_pooler.argtypes = [vp, vp, i32, i32, vp, vp]
     L.plb_loss_fwd.restype = C.c_int
     L.plb_loss_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    L.plb_set_fp8.restype = C.c_int
+    L.plb_set_fp8.argtypes = [vp, i32, vp]
+    L.plb_fp8_state.restype = C.c_int
+    L.plb_fp8_state.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.plb_token_head_steps.restype = i32
     L.plb_token_head_steps.argtypes = [vp]
     L.plb_set_token_head_steps.restype = C.c_int
@@ -202,6 +210,8 @@ def lib():
     L.plb_set_gemm_nt_tile.argtypes = [C.c_int]
     L.plb_set_gemm_nt_prefetch.restype = None
     L.plb_set_gemm_nt_prefetch.argtypes = [C.c_int]
+    L.plb_launch_gemm_nt_fp8.restype = C.c_int
+    L.plb_launch_gemm_nt_fp8.argtypes = [C.POINTER(PlbGemmNT), C.c_int, C.c_int, vp]
     L.plb_launch_gemm_tn.restype = C.c_int
     L.plb_launch_gemm_tn.argtypes = [C.POINTER(PlbGemmTN), vp]
     L.plb_launch_gemm_tn_big.restype = C.c_int

@@ -59,8 +59,11 @@ DEVI f32x16 zero16() {
 
 // Store a wave's transposed accumulator pair X^T[64 c][32 r] (lane = r, registers = c) as rows
 // out[r][0..63] (bf16) through a per-wave LDS patch with 144-B rows, then 16-B coalesced stores.
+// colsum (optional): this wave's 64 column sums of the rows it stored (the values as rounded to bf16) — lane c sums
+// column c of the patch. The engine adds these few partial rows up into the Q/K/V bias gradient instead of re-reading
+// the stacked [L*T, 3H] gradient (906 MB per step at config A).
 DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_t* patch, bf16_t* gout, int ldo,
-                           int rows_valid, int lane) {
+                           int rows_valid, int lane, float* colsum = nullptr) {
   constexpr int PS = 72;  // elements per patch row (144 B)
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -81,6 +84,12 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
     const int id = lane + 64 * i, row = id >> 3, c = id & 7;
     uint4 v = *(const uint4*)&patch[row * PS + c * 8];
     if (row < rows_valid) *(uint4*)(gout + (size_t)row * ldo + c * 8) = v;
+  }
+  if (colsum) {
+    float sacc = 0.f;
+#pragma unroll 8
+    for (int rr = 0; rr < 32; ++rr) sacc += (rr < rows_valid) ? bf2f(patch[rr * PS + lane]) : 0.f;
+    colsum[lane] = sacc;
   }
 }
 
@@ -317,8 +326,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
 #undef KV_STORE
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
   int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
+  // bias-gradient partial row of this wave: [(b * QT + q tile) * 4 + wave][3H], columns hd*64.. of the Q block
+  float* cp = p.colpart ? p.colpart + ((size_t)(b * QT + bx) * 4 + wave) * (3 * H) + hd * 64 : nullptr;
   if (rows_valid > 0)
-    store_transposed(dq0, dq1, p.scale, patch, p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64, p.lddqkv, rows_valid, lane);
+    store_transposed(dq0, dq1, p.scale, patch, p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64, p.lddqkv, rows_valid, lane, cp);
+  else if (cp) cp[lane] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------- backward dK,dV
@@ -437,11 +449,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
 #undef Q_STORE
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
   int rows_valid = S - key0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
+  float* cp = p.colpart ? p.colpart + ((size_t)(b * QT + bx) * 4 + wave) * (3 * H) + hd * 64 : nullptr;
   if (rows_valid > 0) {
     bf16_t* out = p.dqkv + (tok0 + key0) * p.lddqkv + hd * 64;
-    store_transposed(dk0, dk1, p.scale, patch, out + H, p.lddqkv, rows_valid, lane);
+    store_transposed(dk0, dk1, p.scale, patch, out + H, p.lddqkv, rows_valid, lane, cp ? cp + H : nullptr);
     __builtin_amdgcn_wave_barrier();
-    store_transposed(dv0, dv1, 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane);
+    store_transposed(dv0, dv1, 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane, cp ? cp + 2 * H : nullptr);
+  } else if (cp) {
+    cp[H + lane] = 0.f;
+    cp[2 * H + lane] = 0.f;
   }
 }
 

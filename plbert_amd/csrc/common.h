@@ -31,6 +31,19 @@ DEVI float wave_max(float v) {
   return v;
 }
 
+// f32 -> OCP fp8, 4 values -> 4 bytes. The conversion instructions round to nearest even but do NOT saturate (1000 ->
+// 0x7f = NaN in e4m3fn, inf in e5m2: tools/probe_fp8.hip), so clamp to the largest finite value first.
+DEVI uint32_t pack_fp8x4(float a, float b, float c, float d, bool bf8) {
+  const float mx = bf8 ? 57344.f : 448.f;
+  a = fminf(fmaxf(a, -mx), mx); b = fminf(fmaxf(b, -mx), mx); c = fminf(fmaxf(c, -mx), mx); d = fminf(fmaxf(d, -mx), mx);
+  int v = 0;
+  if (bf8) { v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, v, false); v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true); }
+  else { v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false); v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true); }
+  return (uint32_t)v;
+}
+// atomic max of a non-negative float (IEEE order == unsigned order for x >= 0)
+DEVI void atomic_max_abs(float* dst, float v) { atomicMax((unsigned int*)dst, __float_as_uint(v)); }
+
 // gelu_new (HF activations.py:59-66): 0.5 x (1 + tanh(z)), z = sqrt(2/pi) (x + 0.044715 x^3)
 //   = x * sigmoid(2z) = x / (1 + exp2(x * (K1 + K3 x^2))),  K1 = -2 sqrt(2/pi) log2(e), K3 = 0.044715 K1.
 // One v_exp + one v_rcp + 5 plain VALU per value (the GEMM epilogues evaluate it 128x per lane per tile).

@@ -153,7 +153,8 @@ struct PlbEngine {
   int64_t o_dqkv, o_dpre1, o_du, o_dpre2;
   int64_t o_dy0, o_dy1, o_da, o_dctx, o_de;
   int64_t o_hm, o_logm, o_dlog, o_dhm, o_rows, o_tgt, o_w, o_lrows;
-  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_dxe, o_ducol, o_slab2, o_scratch2;
+  int64_t o_slab, o_part1, o_part2, o_parte, o_scratch, o_dxe, o_ducol, o_slab2, o_scratch2, o_qkvcol = 0;
+  int qkvcol_rows = 0;  // partial rows per layer of the Q/K/V bias gradient: max_batch * ceil(max_seq / 128) * 4
   int64_t slab2_floats;
   // token (grapheme) head training: padded copies and the [Tp][NTp] logit / gradient images (NT > 0 only)
   int NTp = 0;
@@ -168,6 +169,13 @@ struct PlbEngine {
   int64_t slab_floats;
   int64_t ws_bytes;
   int ln_blocks, emb_blocks;
+  // fp8 mode (plb_set_fp8): transient 1-byte images of the fp8 GEMMs' activation / gradient operands, fp8 weight copies
+  // and the per-(site, layer) delayed-scaling state [amax | scale | deq] (+ one entry per weight copy)
+  bool fp8_on = false, fp8_ready = false, fp8_bwd_ready = false, fp8_wstale = true;
+  int64_t o_x8 = 0, o_a8 = 0, o_g8 = 0, o_dp8 = 0, o_du8 = 0;
+  int64_t o_wq8 = 0, o_w18 = 0, o_w28 = 0, o_w2T8 = 0, o_w1T8 = 0;
+  int64_t o_f8amax = 0, o_f8scale = 0, o_f8deq = 0;
+  int f8n = 0;
   bool infer = false;           // inference-only workspace: one layer of activations, no gradient stash
   int tok_steps = 0;            // AdamW steps the token head has taken (its own bias correction)
   // data-parallel exchange (plb_comm_*): RCCL communicator, its stream, and the join event of the pieces in flight
@@ -331,6 +339,8 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
     e->o_parte = cv.take((int64_t)e->emb_blocks * 2 * E * 4);
     e->o_dxe = cv.take(Tp * E * 4);
     e->o_ducol = cv.take(L * (2 * Tp / 128) * I * 4);  // column-sum partials of dU from the GEMM epilogue
+    e->qkvcol_rows = c.max_batch * ((c.max_seq + 127) / 128) * 4;
+    e->o_qkvcol = cv.take(L * (int64_t)e->qkvcol_rows * 3 * H * 4);  // ... of dQKV from the attention-backward stores
     e->o_scratch = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);  // colsum partials: up to 512 row splits
     e->o_scratch2 = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);
     {
@@ -360,6 +370,18 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
       e->o_tgrad = cv.take(NTp * H * 4);
     }
   }
+  // fp8 mode: operand images of ONE layer (the bf16 stash stays the backward's source) and the weight copies
+  e->o_x8 = cv.take(Tp * H); e->o_a8 = cv.take(Tp * H); e->o_g8 = cv.take(Tp * I);
+  e->o_wq8 = cv.take(rup(3 * H, 128) * H + 256 * H);
+  e->o_w18 = cv.take(rup(I, 128) * H + 256 * H);
+  e->o_w28 = cv.take(rup(H, 128) * I + 256 * I);
+  if (tr) {
+    e->o_dp8 = cv.take(Tp * H); e->o_du8 = cv.take(Tp * I);
+    e->o_w2T8 = cv.take(rup(I, 128) * H + 256 * H);
+    e->o_w1T8 = cv.take(rup(H, 128) * I + 256 * I);
+  }
+  e->f8n = 5 * (int)L + 5;
+  e->o_f8amax = cv.take(e->f8n * 4); e->o_f8scale = cv.take(e->f8n * 4); e->o_f8deq = cv.take(e->f8n * 4);
   e->ws_bytes = cv.off;
   *out = e;
   return 0;
@@ -417,13 +439,66 @@ extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_av
     if (e_ != hipSuccess) return fail("%s: %s at %s:%d", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// ---- fp8 mode ---------------------------------------------------------------------------------------------------------
+// Sites: activations X (layer input), A (attention block output), G (gelu output) in e4m3; gradients DP (dpre2) and DU
+// in e5m2 (their range within a tensor is what e5m2's five exponent bits are for); weights W* in e4m3.
+enum { F8_X = 0, F8_A, F8_G, F8_DP, F8_DU, F8_NSITE };
+enum { F8W_QKV = 0, F8W_1, F8W_2, F8W_2T, F8W_1T };
+static int f8_site(const PlbEngine* e, int site, int l) { return site * e->L + l; }
+static int f8_w(const PlbEngine* e, int w) { return F8_NSITE * e->L + w; }
+static float* f8_amax(const PlbEngine* e, int i) { return e->at<float>(e->o_f8amax) + i; }
+static float* f8_scale(const PlbEngine* e, int i) { return e->at<float>(e->o_f8scale) + i; }
+static float* f8_deq(const PlbEngine* e, int i) { return e->at<float>(e->o_f8deq) + i; }
+// every GEMM of the fp8 set has a pipeline-tile form at this token count (else the whole call runs in bf16)
+static bool fp8_shapes_ok(const PlbEngine* e, int64_t Tp) {
+  const int64_t H = e->H, I = e->I;
+  if (!(H == 768 || H == 1024) || I % 256 || H % 128 || I % 128) return false;
+  if (Tp % 128) return false;
+  return (3 * H) % 384 == 0 || (3 * H) % 256 == 0;
+}
+// per-tensor e4m3 copies of the fp8 GEMMs' weights (exact amax: the weights are known)
+static int fp8_quantize_weights(PlbEngine* e, hipStream_t s) {
+  const int H = e->H, I = e->I;
+  struct W { int w; const void* src; int bf16; int rows, cols; int64_t dst; } ws[5] = {
+      {F8W_QKV, e->par(PLB_Q_W), 0, 3 * H, H, e->o_wq8},
+      {F8W_1, e->par(PLB_FFN_W), 0, I, H, e->o_w18},
+      {F8W_2, e->par(PLB_FFNO_W), 0, H, I, e->o_w28},
+      {F8W_2T, e->infer ? nullptr : e->at<bf16_t>(e->o_w2T), 1, I, H, e->o_w2T8},
+      {F8W_1T, e->infer ? nullptr : e->at<bf16_t>(e->o_w1T), 1, H, I, e->o_w1T8}};
+  HIPTRY(hipMemsetAsync(f8_amax(e, f8_w(e, 0)), 0, 5 * sizeof(float), s));
+  for (auto& w : ws) {
+    if (!w.src) continue;
+    TRY(plb_launch_amax(w.src, w.bf16, (size_t)w.rows, w.cols, w.cols, f8_amax(e, f8_w(e, w.w)), s));
+  }
+  TRY(plb_launch_fp8_scales(f8_amax(e, f8_w(e, 0)), f8_scale(e, f8_w(e, 0)), f8_deq(e, f8_w(e, 0)), 5, 448.f, s));
+  for (auto& w : ws) {
+    if (!w.src) continue;
+    TRY(plb_launch_quantize(w.src, w.bf16, (size_t)w.rows, w.cols, w.cols, f8_scale(e, f8_w(e, w.w)), e->at<uint8_t>(w.dst),
+                            w.cols, 0, s));
+  }
+  e->fp8_wstale = false;
+  return 0;
+}
+// end of a call in fp8 mode: this call's maxima become the next call's scales (delayed scaling, history 1)
+static int fp8_update_scales(PlbEngine* e, hipStream_t s) {
+  const int L = e->L;
+  TRY(plb_launch_fp8_scales(f8_amax(e, 0), f8_scale(e, 0), f8_deq(e, 0), 3 * L, 448.f, s));          // X, A, G: e4m3
+  TRY(plb_launch_fp8_scales(f8_amax(e, 3 * L), f8_scale(e, 3 * L), f8_deq(e, 3 * L), 2 * L, 57344.f, s));  // DP, DU: e5m2
+  return 0;
+}
+
 static int sync_transposes(PlbEngine* e, hipStream_t s) {
   const int H = e->H, I = e->I, E = e->E;
+
   if (e->NT) {  // bias of the token head padded to NTp columns (fused GEMM + CE passes)
     if (!e->tok_pad_zeroed) HIPTRY(hipMemsetAsync(e->at<float>(e->o_bt), 0, (size_t)e->NTp * 4, s));
     HIPTRY(hipMemcpyAsync(e->at<float>(e->o_bt), e->par(PLB_TOK_B), (size_t)e->NT * 4, hipMemcpyDeviceToDevice, s));
   }
-  if (e->infer) { e->tok_pad_zeroed = true; return 0; }  // the transposed copies serve the backward only
+  if (e->infer) {  // the transposed copies serve the backward only
+    e->tok_pad_zeroed = true;
+    if (e->fp8_on) return fp8_quantize_weights(e, s);
+    return 0;
+  }
   // fused QKV [3H,H] -> [H,3H]; the three tensors are adjacent in the flat buffer
   TRY(plb_launch_transpose_cast(e->par(PLB_Q_W), 3 * H, H, e->at<bf16_t>(e->o_wqkvT), 3 * H, s));
   TRY(plb_launch_transpose_cast(e->par(PLB_DENSE_W), H, H, e->at<bf16_t>(e->o_wdT), H, s));
@@ -436,6 +511,27 @@ static int sync_transposes(PlbEngine* e, hipStream_t s) {
     TRY(plb_launch_transpose_cast(e->par(PLB_TOK_W), e->NT, H, e->at<bf16_t>(e->o_wtT), e->NTp, s));
   }
   e->tok_pad_zeroed = true;
+  if (e->fp8_on) return fp8_quantize_weights(e, s);
+  return 0;
+}
+
+extern "C" int plb_set_fp8(PlbEngine* e, int32_t on, void* stream) {
+  if (!e || !e->ws) return fail("plb_set_fp8: engine not bound");
+  if (on && !(e->H == 768 || e->H == 1024)) return fail("plb_set_fp8: the fp8 path needs hidden_size 768 or 1024");
+  if (on && !e->fp8_on) {  // the first call afterwards runs in bf16 and calibrates the scales
+    hipStream_t s = (hipStream_t)stream;
+    HIPTRY(hipMemsetAsync(f8_amax(e, 0), 0, (size_t)e->f8n * 4, s));
+    e->fp8_ready = false;      // activation sites: armed by the first forward
+    e->fp8_bwd_ready = false;  // gradient sites: armed by the first backward
+    e->fp8_wstale = true;
+  }
+  e->fp8_on = on != 0;
+  return 0;
+}
+extern "C" int plb_fp8_state(const PlbEngine* e, int32_t* enabled, int32_t* calibrated) {
+  if (!e) return fail("plb_fp8_state: null engine");
+  if (enabled) *enabled = e->fp8_on;
+  if (calibrated) *calibrated = e->fp8_ready;
   return 0;
 }
 
@@ -453,13 +549,33 @@ static int check_shape(const PlbEngine* e, int B, int S, const char* who) {
   return 0;
 }
 
+// One NT GEMM of the fp8 set: the fp8 launch when the call runs in fp8 mode (A8 / B8 images, their dequantisation
+// factors), else the bf16 launch on A / B. g carries everything else (shapes, bias, residual, outputs).
+struct F8Op { const uint8_t* A8; const uint8_t* B8; const float* deq_a; const float* deq_b; int a_bf8; };
+static int gemm_nt_any(PlbGemmNT* g, int act, const F8Op* f8, hipStream_t s) {
+  if (!f8) return plb_launch_gemm_nt(g, act, 0, s);
+  PlbGemmNT q = *g;
+  q.A = reinterpret_cast<const bf16_t*>(f8->A8); q.B = reinterpret_cast<const bf16_t*>(f8->B8);
+  q.deq_a = f8->deq_a; q.deq_b = f8->deq_b;
+  return plb_launch_gemm_nt_fp8(&q, act, f8->a_bf8, s);
+}
+
 // Embeddings + L applications of the shared layer. stash: keep every layer's activations (training)
 // or reuse the layer-0 slots (inference). Returns the final hidden buffer in *xout.
+// fp8 mode: the QKV and the two FFN GEMMs run on e4m3 images — the LayerNorm kernels and the gelu epilogue write them
+// beside their bf16 outputs, each with the scale its site learnt in the previous call; a calibration call (the first
+// after plb_set_fp8) runs in bf16 and only records the maxima.
 static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths, int B, int S, bool stash, bf16_t** xout,
                        hipStream_t s) {
   const int E = e->E, H = e->H, I = e->I, L = e->L;
   const int T = B * S;
   const int64_t Tp = rup(T, 128);
+  const bool f8 = e->fp8_on && e->fp8_ready && fp8_shapes_ok(e, Tp);
+  const bool calib = e->fp8_on && !e->fp8_ready;
+  if (e->fp8_on && e->fp8_wstale) TRY(fp8_quantize_weights(e, s));
+  uint8_t* x8 = e->at<uint8_t>(e->o_x8);
+  uint8_t* a8 = e->at<uint8_t>(e->o_a8);
+  uint8_t* g8 = e->at<uint8_t>(e->o_g8);
   PlbEmbed em;
   memset(&em, 0, sizeof(em));
   em.ids = ids; em.T = T; em.S = S; em.E = E; em.V = e->V;
@@ -474,6 +590,10 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
   g.A = em.out; g.lda = E; g.B = e->wbf(PLB_MAP_W); g.ldb = E; g.M = (int)Tp; g.N = H; g.K = E; g.Mstore = (int)Tp;
   g.bias = e->par(PLB_MAP_B); g.C = xall; g.ldc = H;
   TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+  if (f8) {  // layer 0 reads the map-in output, which no LayerNorm produced: one quantisation pass
+    TRY(plb_launch_quantize(xall, 1, (size_t)T, H, H, f8_scale(e, f8_site(e, F8_X, 0)), x8, H, 0, s));
+    TRY(plb_launch_amax(xall, 1, (size_t)T, H, H, f8_amax(e, f8_site(e, F8_X, 0)), s));
+  }
 
   for (int l = 0; l < L; ++l) {
     const int64_t sl = stash ? l : 0;
@@ -486,11 +606,14 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     bf16_t* u = e->at<bf16_t>(e->o_u) + sl * Tp * I;
     bf16_t* gl = e->at<bf16_t>(e->o_g) + sl * Tp * I;
     bf16_t* pre2 = e->at<bf16_t>(e->o_pre2) + sl * Tp * H;
+    const int sX = f8_site(e, F8_X, l), sA = f8_site(e, F8_A, l), sG = f8_site(e, F8_G, l);
+    if (calib) TRY(plb_launch_amax(x, 1, (size_t)T, H, H, f8_amax(e, sX), s));
     // fused QKV projection
     memset(&g, 0, sizeof(g));
     g.A = x; g.lda = H; g.B = e->wbf(PLB_Q_W); g.ldb = H; g.M = (int)Tp; g.N = 3 * H; g.K = H; g.Mstore = (int)Tp;
     g.bias = e->par(PLB_Q_B); g.C = qkv; g.ldc = 3 * H;
-    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    F8Op oq = {x8, e->at<uint8_t>(e->o_wq8), f8_deq(e, sX), f8_deq(e, f8_w(e, F8W_QKV)), 0};
+    TRY(gemm_nt_any(&g, 0, f8 ? &oq : nullptr, s));
     PlbAttn at;
     memset(&at, 0, sizeof(at));
     at.qkv = qkv; at.ldqkv = 3 * H; at.lengths = lengths; at.B = B; at.S = S; at.NH = e->NH; at.H = H;
@@ -507,20 +630,30 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.beta = e->par(PLB_LN1_B); ln.eps = e->c.layer_norm_eps;
     ln.y = a; ln.ldy = H; ln.T = T; ln.H = H;
     ln.mean = e->at<float>(e->o_mean1) + sl * Tp; ln.rstd = e->at<float>(e->o_rstd1) + sl * Tp;
+    if (f8) { ln.out8 = a8; ln.ld8 = H; ln.q_scale = f8_scale(e, sA); ln.q_amax = f8_amax(e, sA); }
     TRY(plb_launch_ln_fwd(&ln, s));
+    if (calib) TRY(plb_launch_amax(a, 1, (size_t)T, H, H, f8_amax(e, sA), s));
     // FFN: u = a W1^T + b1, g = gelu_new(u); pre2 = g W2^T + b2 + a
     memset(&g, 0, sizeof(g));
     g.A = a; g.lda = H; g.B = e->wbf(PLB_FFN_W); g.ldb = H; g.M = (int)Tp; g.N = I; g.K = H; g.Mstore = (int)Tp;
     g.bias = e->par(PLB_FFN_B); g.C = u; g.ldc = I; g.C2 = gl; g.ldc2 = I;
-    TRY(plb_launch_gemm_nt(&g, 1, 0, s));
+    if (f8) { g.C8 = g8; g.ldc8 = I; g.q_scale = f8_scale(e, sG); g.q_amax = f8_amax(e, sG); g.c8_bf8 = 0; }
+    F8Op o1 = {a8, e->at<uint8_t>(e->o_w18), f8_deq(e, sA), f8_deq(e, f8_w(e, F8W_1)), 0};
+    TRY(gemm_nt_any(&g, 1, f8 ? &o1 : nullptr, s));
+    if (calib) TRY(plb_launch_amax(gl, 1, (size_t)T, I, I, f8_amax(e, sG), s));
     memset(&g, 0, sizeof(g));
     g.A = gl; g.lda = I; g.B = e->wbf(PLB_FFNO_W); g.ldb = I; g.M = (int)Tp; g.N = H; g.K = I; g.Mstore = (int)Tp;
     g.bias = e->par(PLB_FFNO_B); g.res = a; g.ldr = H; g.C = pre2; g.ldc = H;
-    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    F8Op o2 = {g8, e->at<uint8_t>(e->o_w28), f8_deq(e, sG), f8_deq(e, f8_w(e, F8W_2)), 0};
+    TRY(gemm_nt_any(&g, 0, f8 ? &o2 : nullptr, s));
     memset(&ln, 0, sizeof(ln));
     ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.beta = e->par(PLB_LN2_B); ln.eps = e->c.layer_norm_eps;
     ln.y = y; ln.ldy = H; ln.T = T; ln.H = H;
     ln.mean = e->at<float>(e->o_mean2) + sl * Tp; ln.rstd = e->at<float>(e->o_rstd2) + sl * Tp;
+    if (f8 && l + 1 < L) {  // the next application's input image
+      const int sN = f8_site(e, F8_X, l + 1);
+      ln.out8 = x8; ln.ld8 = H; ln.q_scale = f8_scale(e, sN); ln.q_amax = f8_amax(e, sN);
+    }
     TRY(plb_launch_ln_fwd(&ln, s));
     *xout = y;
   }
@@ -550,6 +683,10 @@ extern "C" int plb_forward(PlbEngine* e, const int64_t* ids, const int32_t* leng
     g.A = x; g.lda = H; g.B = e->wbf(PLB_TOK_W); g.ldb = H; g.M = (int)Tp; g.N = e->NT; g.K = H; g.Mstore = T;
     g.bias = e->par(PLB_TOK_B); g.Cf = token_logits; g.ldcf = e->NT;
     TRY(plb_launch_gemm_nt(&g, 0, 1, s));
+  }
+  if (e->fp8_on) {
+    TRY(fp8_update_scales(e, s));
+    e->fp8_ready = true;
   }
   return 0;
 }
@@ -731,12 +868,25 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       TRY(plb_launch_gemm_nt(&g, 0, 0, s));
     }
   }
-  if (!backward) return 0;
+  if (!backward) {
+    if (e->fp8_on) {  // forward-only call in fp8 mode: activation sites only (gradient sites saw nothing and keep theirs)
+      TRY(fp8_update_scales(e, s));
+      e->fp8_ready = true;
+    }
+    return 0;
+  }
 
   // ---- layers in reverse --------------------------------------------------------------------------------
-  const int du_rows = plb_gemm_nt_colpart_rows((int)Tp, I, H);  // ffn.bias gradient from the dU GEMM's epilogue
+  // fp8 mode: the two FFN dX GEMMs (dU = dpre2 W2, dA = dU W1) read e5m2 images of their gradient operand, written by
+  // the LayerNorm backward and by the gelu-backward epilogue; everything else stays bf16.
+  const bool f8 = e->fp8_on && e->fp8_bwd_ready && fp8_shapes_ok(e, Tp);
+  const bool calib = e->fp8_on && !e->fp8_bwd_ready;
+  // ffn.bias gradient from the dU GEMM's epilogue: 2 partial rows per row tile of the kernel that runs it
+  const int du_rows = f8 ? 2 * (int)(Tp / 128) : plb_gemm_nt_colpart_rows((int)Tp, I, H);
   bf16_t* da = e->at<bf16_t>(e->o_da);
   bf16_t* dctx = e->at<bf16_t>(e->o_dctx);
+  uint8_t* dp8 = e->at<uint8_t>(e->o_dp8);
+  uint8_t* du8 = e->at<uint8_t>(e->o_du8);
   for (int l = L - 1; l >= 0; --l) {
     bf16_t* qkv = e->at<bf16_t>(e->o_qkv) + (int64_t)l * Tp * 3 * H;
     bf16_t* ctx = e->at<bf16_t>(e->o_ctx) + (int64_t)l * Tp * H;
@@ -747,24 +897,31 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     bf16_t* dpre1 = e->at<bf16_t>(e->o_dpre1) + (int64_t)l * Tp * H;
     bf16_t* du = e->at<bf16_t>(e->o_du) + (int64_t)l * Tp * I;
     bf16_t* dpre2 = e->at<bf16_t>(e->o_dpre2) + (int64_t)l * Tp * H;
+    const int sDP = f8_site(e, F8_DP, l), sDU = f8_site(e, F8_DU, l);
     PlbLayerNorm ln;
     memset(&ln, 0, sizeof(ln));
     ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
     ln.mean = e->at<float>(e->o_mean2) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd2) + (int64_t)l * Tp;
     ln.dy = dy; ln.lddy = H; ln.dx = dpre2; ln.lddx = H;
     ln.partials = e->at<float>(e->o_part2) + (int64_t)l * e->ln_blocks * 3 * H; ln.nblocks = e->ln_blocks;
+    if (f8) { ln.out8 = dp8; ln.ld8 = H; ln.q_scale = f8_scale(e, sDP); ln.q_amax = f8_amax(e, sDP); }
     TRY(plb_launch_ln_bwd(&ln, s));
+    if (calib) TRY(plb_launch_amax(dpre2, 1, (size_t)T, H, H, f8_amax(e, sDP), s));
     // dU = (dpre2 · W2) ∘ gelu'(u)
     memset(&g, 0, sizeof(g));
     g.A = dpre2; g.lda = H; g.B = e->at<bf16_t>(e->o_w2T); g.ldb = H; g.M = (int)Tp; g.N = I; g.K = H; g.Mstore = (int)Tp;
     g.aux = u; g.ldaux = I; g.C = du; g.ldc = I;
     if (du_rows > 0) g.colpart = e->at<float>(e->o_ducol) + (int64_t)l * du_rows * I;
-    TRY(plb_launch_gemm_nt(&g, 2, 0, s));
+    if (f8) { g.C8 = du8; g.ldc8 = I; g.q_scale = f8_scale(e, sDU); g.q_amax = f8_amax(e, sDU); g.c8_bf8 = 1; }
+    F8Op ou = {dp8, e->at<uint8_t>(e->o_w2T8), f8_deq(e, sDP), f8_deq(e, f8_w(e, F8W_2T)), 1};
+    TRY(gemm_nt_any(&g, 2, f8 ? &ou : nullptr, s));
+    if (calib) TRY(plb_launch_amax(du, 1, (size_t)T, I, I, f8_amax(e, sDU), s));
     // dA = dU · W1 + dpre2
     memset(&g, 0, sizeof(g));
     g.A = du; g.lda = I; g.B = e->at<bf16_t>(e->o_w1T); g.ldb = I; g.M = (int)Tp; g.N = H; g.K = I; g.Mstore = (int)Tp;
     g.res = dpre2; g.ldr = H; g.C = da; g.ldc = H;
-    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    F8Op oa = {du8, e->at<uint8_t>(e->o_w1T8), f8_deq(e, sDU), f8_deq(e, f8_w(e, F8W_1T)), 1};
+    TRY(gemm_nt_any(&g, 0, f8 ? &oa : nullptr, s));
     memset(&ln, 0, sizeof(ln));
     ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
     ln.mean = e->at<float>(e->o_mean1) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd1) + (int64_t)l * Tp;
@@ -781,6 +938,7 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     at.qkv = qkv; at.ldqkv = 3 * H; at.lengths = lengths; at.B = B; at.S = S; at.NH = e->NH; at.H = H; at.scale = 0.125f;
     at.ctx = ctx; at.ldctx = H; at.lse = e->at<float>(e->o_lse) + (int64_t)l * B * e->NH * S;
     at.dctx = dctx; at.lddctx = H; at.delta = e->at<float>(e->o_delta); at.dqkv = dqkv; at.lddqkv = 3 * H;
+    at.colpart = e->at<float>(e->o_qkvcol) + (int64_t)l * (B * ((S + 127) / 128) * 4) * 3 * H;
     TRY(plb_launch_attn_bwd(&at, s));
     if (Tp > T) HIPTRY(hipMemsetAsync(dqkv + (int64_t)T * 3 * H, 0, (size_t)(Tp - T) * 3 * H * 2, s));
     // dX = dQKV · Wqkv + dpre1
@@ -789,6 +947,11 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     g.Mstore = (int)Tp; g.res = dpre1; g.ldr = H; g.C = dy_other; g.ldc = H;
     TRY(plb_launch_gemm_nt(&g, 0, 0, s));
     bf16_t* tmp = dy; dy = dy_other; dy_other = tmp;
+  }
+  if (e->fp8_on) {  // this call's maxima become the next call's scales; a calibration call arms the fp8 path
+    TRY(fp8_update_scales(e, s));
+    e->fp8_ready = true;
+    e->fp8_bwd_ready = true;
   }
   return backward_tail(e, masked_ids, dy, B, S, du_rows, s);
 }
@@ -831,7 +994,9 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   TRY(plb_launch_colsum(em.partials, 0, (size_t)e->emb_blocks, 2 * E, 2 * E, e->grd(PLB_EMB_LN_W), 2 * E, 0, scratch2, 1, s2));
   // token_type row 0 receives every token's gradient = the column sums of dpos
   TRY(plb_launch_colsum(e->grd(PLB_POS_EMB), 0, (size_t)e->P, E, E, e->grd(PLB_TYPE_EMB), E, 0, scratch2, 1, s2));
-  TRY(plb_launch_colsum(e->at<bf16_t>(e->o_dqkv), 1, (size_t)Mtot, 3 * H, 3 * H, e->grd(PLB_Q_B), 3 * H, 0, scratch2, 64, s2));
+  // Q/K/V biases: the attention-backward kernels left column sums of every 32-row patch they stored ([L][B*QT*4][3H])
+  TRY(plb_launch_colsum(e->at<float>(e->o_qkvcol), 0, (size_t)L * (B * ((S + 127) / 128) * 4), 3 * H, 3 * H, e->grd(PLB_Q_B),
+                        3 * H, 0, scratch2, 32, s2));
   if (du_rows > 0)
     TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 16, s2));
   else

@@ -20,577 +20,12 @@
 // by measurement (plb_launch_gemm_nt_big): "interleaved" (fragment reads of the next phase and the DMA
 // issues dealt into the MFMA shadows, one barrier per phase) and "staggered" (two barriers per phase, the
 // two waves of a SIMD half a phase apart) — see the comments at the loops.
-#include "common.h"
-#include "plbert_kernels.h"
-#include "gemm_epilogue.h"
+#include "gemm_nt_pipeline.h"
 
 // Timing experiments only (tools/build_dbg.sh): -DNT_DBG=<bit mask> 1 no MFMA, 2 no fragment reads, 4 no DMA
 // after the prologue, 8 no barriers in the K loop (results are garbage with any of those), 16 print the shader
 // clock over the K loop (results stay valid). The shipped library has 0.
-#ifndef NT_DBG
-#define NT_DBG 0
-#endif
-
 namespace {
-
-constexpr int HT = 128 * 64;  // elements per half-tile (16 KiB)
-constexpr int RING = 10;      // half-tile slots of the LDS ring used by the NT kernel (160 KiB)
-DEVI int ring_slot(int x) { return x >= 2 * RING ? x - 2 * RING : (x >= RING ? x - RING : x); }
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// Retire this wave's LDS reads, then barrier: a DMA issued by another wave after the barrier may
-// overwrite what those reads were fetching. The "memory" clobber keeps ds_read / global_load_lds on
-// their side of the barrier; sched_barrier pins the register-only MFMAs as well.
-// The wait is the builtin (0xC07F = lgkmcnt(0), vmcnt / expcnt untouched) so hipcc's own waitcnt tracking
-// knows the LDS reads have retired; written as asm it would re-wait with lgkmcnt(0) at the first MFMA that
-// uses those fragments, which would also stall on the reads just issued for the next phase.
-#define BARRIER()                                        \
-  do {                                                   \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                  \
-    if (!(NT_DBG & 8)) asm volatile("s_barrier" ::: "memory"); \
-  } while (0)
-#define PIN() __builtin_amdgcn_sched_barrier(0)
-
-// V selects the tile: 2 -> 256x256 (2 A halves, 2 B halves), 3 -> 128x384 (1 A, 3 B), 1 -> 128x256 (1 A, 2 B;
-// three half-tiles per K-tile, two phases, two half-tiles in flight: for shapes where the larger tiles
-// would leave CUs idle, e.g. N = 1024 at M = 8192).
-template <int V, int ACT, bool OUTF32, bool PF>
-__global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
-  constexpr int NAH = (V == 2) ? 2 : 1;
-  constexpr int NBH = (V == 3) ? 3 : 2;
-  constexpr int TM = NAH * 128, TN = NBH * 128;
-  constexpr int NH = NAH + NBH;  // half-tiles per K-tile, consumed in the order A0 B0 B1 [A1 | B2]
-  __shared__ __attribute__((aligned(16))) bf16_t smem[RING * HT];  // 160 KiB: the whole LDS of a CU
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = uw >> 2, wn = uw & 3;
-  const int nbn = p.N / TN;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int bm = logical / nbn, bn = logical % nbn;
-  const int nk = p.K >> 6;
-#if NT_DBG & 16
-  const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-
-  // ---- staging: each wave DMAs rows [(2w+j)*8, +8) of a half-tile, j = 0,1 (1 KiB per instruction);
-  // the XOR swizzle of the image is applied to the per-lane SOURCE chunk
-  const int drow = lane >> 3;
-  const int ch0 = ((lane & 7) ^ ((lane >> 4) & 7)) * 8;
-  const int ch1 = ((lane & 7) ^ ((4 + (lane >> 4)) & 7)) * 8;
-  const bf16_t* gA0 = p.A + (size_t)(bm * TM + (2 * uw) * 8 + drow) * p.lda + ch0;
-  const bf16_t* gA1 = p.A + (size_t)(bm * TM + (2 * uw + 1) * 8 + drow) * p.lda + ch1;
-  const bf16_t* gB0 = p.B + (size_t)(bn * TN + (2 * uw) * 8 + drow) * p.ldb + ch0;
-  const bf16_t* gB1 = p.B + (size_t)(bn * TN + (2 * uw + 1) * 8 + drow) * p.ldb + ch1;
-  const size_t hA = (size_t)128 * p.lda, hB = (size_t)128 * p.ldb;
-  const int dst0 = (2 * uw) * 8 * 64, dst1 = (2 * uw + 1) * 8 * 64;
-#define STAGE_A(slot, h, kt)                                                                                  \
-  do {                                                                                                        \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (h) * hA + (size_t)(kt) * 64),                            \
-                                     (lptr_t)&smem[(slot) * HT + dst0], 16, 0, 0);                            \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (h) * hA + (size_t)(kt) * 64),                            \
-                                     (lptr_t)&smem[(slot) * HT + dst1], 16, 0, 0);                            \
-  } while (0)
-#define STAGE_B(slot, h, kt)                                                                                  \
-  do {                                                                                                        \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gB0 + (h) * hB + (size_t)(kt) * 64),                            \
-                                     (lptr_t)&smem[(slot) * HT + dst0], 16, 0, 0);                            \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gB1 + (h) * hB + (size_t)(kt) * 64),                            \
-                                     (lptr_t)&smem[(slot) * HT + dst1], 16, 0, 0);                            \
-  } while (0)
-// half-tile i of a K-tile, in consumption order: A0, B0, B1, then A1 (256x256) or B2 (128x384)
-#define STAGE_I(i, slot, kt)                                              \
-  do {                                                                    \
-    if (V == 2 && (i) == 3) STAGE_A(slot, 1, kt);                         \
-    else if ((i) == 0) STAGE_A(slot, 0, kt);                              \
-    else STAGE_B(slot, (i) - 1, kt);                                      \
-  } while (0)
-// issue half-tile number NH*t + c of the stream (c is a literal), if it exists
-#define ISSUE(c)                                                          \
-  do {                                                                    \
-    if ((!(NT_DBG & 4) || PRO) && NH * t + (c) < htot) STAGE_I((c) % NH, ring_slot(rb + (c)), t + (c) / NH); \
-  } while (0)
-
-  // ---- fragment reads: row-in-half = wm*64 + mi*16 + frow (A) / wn*32 + ni*16 + frow (B);
-  // stored chunk = (kk*4 + fq) ^ ((frow>>1)&7)
-  const int frow = lane & 15, fq = lane >> 4, fsw = (frow >> 1) & 7;
-  const int offA = (wm * 64 + frow) * 64, offB = (wn * 32 + frow) * 64;
-  const int c0 = ((0 + fq) ^ fsw) << 3, c1 = ((4 + fq) ^ fsw) << 3;
-  // two A and two B fragment buffers (indices are literals everywhere: plain registers). The prefetching
-  // loop ping-pongs them; the staggered loop uses afr[0] and both B buffers.
-  bf16x8 afr[2][4][2], bfr[2][2][2];
-  if (NT_DBG & 2) {
-    __builtin_memset(afr, 0, sizeof(afr));
-    __builtin_memset(bfr, 0, sizeof(bfr));
-  }
-#define READ_A(ab, slot)                                                             \
-  do {                                                                               \
-    const bf16_t* s_ = &smem[(slot) * HT + offA];                                    \
-    if (!(NT_DBG & 2)) _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                               \
-      afr[ab][mi][0] = *(const bf16x8*)&s_[mi * 16 * 64 + c0];                       \
-      afr[ab][mi][1] = *(const bf16x8*)&s_[mi * 16 * 64 + c1];                       \
-    }                                                                                \
-  } while (0)
-#define READ_B(bb, slot)                                                             \
-  do {                                                                               \
-    const bf16_t* s_ = &smem[(slot) * HT + offB];                                    \
-    if (!(NT_DBG & 2)) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                               \
-      bfr[bb][ni][0] = *(const bf16x8*)&s_[ni * 16 * 64 + c0];                       \
-      bfr[bb][ni][1] = *(const bf16x8*)&s_[ni * 16 * 64 + c1];                       \
-    }                                                                                \
-  } while (0)
-
-  f32x4 acc[NAH][4][NBH][2];  // [mh][mi][nh][ni]
-#pragma unroll
-  for (int a = 0; a < NAH; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int c = 0; c < NBH; ++c)
-#pragma unroll
-        for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // swapped MFMA operands: D[row = n][col = m] -> each lane owns 4 consecutive n of one row m
-#define MFMA_Q(mh, nh, ab, bb)                                                                                 \
-  do {                                                                                                         \
-    if (!(NT_DBG & 1)) _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
-      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                         \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
-          acc[mh][mi][nh][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[bb][ni][kk], afr[ab][mi][kk],     \
-                                                                        acc[mh][mi][nh][ni], 0, 0, 0);         \
-  } while (0)
-#define MFMA_PART(mh, nh, bb)            \
-  do {                                   \
-    BARRIER(); PIN();                    \
-    __builtin_amdgcn_s_setprio(1);       \
-    MFMA_Q(mh, nh, 0, bb);               \
-    __builtin_amdgcn_s_setprio(0);       \
-    PIN(); BARRIER(); PIN();             \
-  } while (0)
-// prefetching form of a phase: one barrier, then the fragment reads of the NEXT phase are issued ahead
-// of this phase's 16 MFMAs and complete underneath them (retired by the next BARRIER's lgkmcnt(0))
-#define PHASE(reads, mh, nh, ab, bb)     \
-  do {                                   \
-    BARRIER(); PIN();                    \
-    reads;                               \
-    __builtin_amdgcn_s_setprio(1);       \
-    MFMA_Q(mh, nh, ab, bb);              \
-    __builtin_amdgcn_s_setprio(0);       \
-    PIN();                               \
-  } while (0)
-// Wait until everything but the newest N DMA instructions has landed (N = 2 x half-tiles allowed in
-// flight); once the stream has run out (an expected issue was skipped) drain completely.
-#define LANDED(more, N)                                                        \
-  do {                                                                         \
-    if (more) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");            \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
-  } while (0)
-
-  // ---- The half-tile stream. Half-tile number h = NH*t + i (K-tile t, i-th in consumption order)
-  // lives in ring slot h % 10. A slot may be re-filled once the phase that read its previous occupant
-  // h - 10 has finished, so at the start of phase P the stream may advance to (last half-tile read
-  // before P) + 10. That keeps 5 (128x384), 6 (256x256, 128x256) half-tiles = 80-96 KiB in flight at
-  // the wait that precedes a K-tile, against 3 with a double-buffered 128 KiB layout.
-  const int htot = NH * nk;
-  int rb = 0;  // (NH * t) % RING
-  bool PRO = true;  // NT_DBG only
-  {
-    const int t = 0;
-    ISSUE(0); ISSUE(1); ISSUE(2); ISSUE(3); ISSUE(4); ISSUE(5); ISSUE(6); ISSUE(7); ISSUE(8);
-    if constexpr (V == 2) {
-      ISSUE(9);
-      LANDED(htot > 9, 12);   // K-tile 0 = half-tiles 0..3
-    } else if constexpr (V == 3) {
-      LANDED(htot > 8, 10);   // half-tiles 0..3
-    } else {
-      LANDED(htot > 8, 12);   // half-tiles 0..2
-    }
-  }
-  BARRIER();
-  PRO = false;
-  if constexpr (PF) {
-    // ---- interleaved loop (default). Measured on the staggered loop (tools/build_dbg.sh): MFMA, fragment
-    // reads and DMA cost 0.64 + 0.41 + 0.29 us per K-tile and the K-tile takes their SUM — a wave issues in
-    // order, so a burst of 4-12 ds_read_b128 ahead of its MFMAs holds them back until the LDS has
-    // accepted every wave's burst. Here a phase is {BARRIER, 16 MFMAs}, and the fragment reads for the
-    // NEXT phase and the DMA issues are dealt one per MFMA into the shadows of those MFMAs (the guide's
-    // rule: <= 2 ds_read_b128 per MFMA gap are free). sched_barrier pins that order. Fragment buffers
-    // ping-pong, so the K loop is written for two K-tiles. One barrier per phase, no stagger.
-    //  RAW: the vmcnt wait for K-tile t+1 ends the phase before the one whose shadows first read it, so a
-    //       BARRIER lies between every wave's wait and any wave's read; it leaves only half-tiles beyond
-    //       K-tile t+1 in flight, so the later phases of that K-tile need no wait of their own.
-    //  WAR: reads issued in phase P retire at BARRIER(P+1) (lgkmcnt(0)); the slot is re-filled by a DMA
-    //       issued after BARRIER(P+2) at the earliest.
-    //  The last K-tile's "next" reads fetch stale slots (valid LDS addresses, values unused).
-    READ_A(0, 0);
-    READ_B(0, 1);
-    int t = 0;
-#define NEXT_T() do { ++t; rb += NH; rb = rb >= RING ? rb - RING : rb; } while (0)
-// one MFMA of the 16 of a phase: j -> (kk, mi, ni)
-#define MF(mh, nh, ab, bb, j)                                                                          \
-  do {                                                                                                 \
-    if (!(NT_DBG & 1))                                                                                   \
-      acc[mh][((j) >> 1) & 3][nh][(j) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                  \
-          bfr[bb][(j) & 1][(j) >> 3], afr[ab][((j) >> 1) & 3][(j) >> 3], acc[mh][((j) >> 1) & 3][nh][(j) & 1], 0, 0, 0); \
-    PIN();                                                                                             \
-  } while (0)
-// one ds_read_b128 of an A half (i = 0..7) / a B half (i = 0..3)
-#define RA(ab, slot, i)                                                                                \
-  do {                                                                                                 \
-    if (!(NT_DBG & 2))                                                                                   \
-      afr[ab][(i) >> 1][(i) & 1] = *(const bf16x8*)&smem[(slot) * HT + offA + ((i) >> 1) * 16 * 64 + (((i) & 1) ? c1 : c0)]; \
-    PIN();                                                                                             \
-  } while (0)
-#define RB(bb, slot, i)                                                                                \
-  do {                                                                                                 \
-    if (!(NT_DBG & 2))                                                                                   \
-      bfr[bb][(i) >> 1][(i) & 1] = *(const bf16x8*)&smem[(slot) * HT + offB + ((i) >> 1) * 16 * 64 + (((i) & 1) ? c1 : c0)]; \
-    PIN();                                                                                             \
-  } while (0)
-#define IS(c) do { ISSUE(c); PIN(); } while (0)
-// a phase: barrier, then MFMA j followed by shadow statement sj
-#define PH(mh, nh, ab, bb, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)      \
-  do {                                                                                                 \
-    BARRIER(); PIN();                                                                                  \
-    MF(mh, nh, ab, bb, 0); s0; MF(mh, nh, ab, bb, 1); s1; MF(mh, nh, ab, bb, 2); s2; MF(mh, nh, ab, bb, 3); s3;       \
-    MF(mh, nh, ab, bb, 4); s4; MF(mh, nh, ab, bb, 5); s5; MF(mh, nh, ab, bb, 6); s6; MF(mh, nh, ab, bb, 7); s7;       \
-    MF(mh, nh, ab, bb, 8); s8; MF(mh, nh, ab, bb, 9); s9; MF(mh, nh, ab, bb, 10); s10; MF(mh, nh, ab, bb, 11); s11;   \
-    MF(mh, nh, ab, bb, 12); s12; MF(mh, nh, ab, bb, 13); s13; MF(mh, nh, ab, bb, 14); s14; MF(mh, nh, ab, bb, 15); s15; \
-  } while (0)
-#define NOP_ (void)0
-    // 128x256 (A B0 | B1): ph1 reads B1(t), ph2 reads A(t+1), B0(t+1)
-#define STEP1(ab)                                                                                       \
-  do {                                                                                                  \
-    const int sB1 = ring_slot(rb + 2), sA = ring_slot(rb + 3), sB0 = ring_slot(rb + 4);                 \
-    PH(0, 0, ab, 0, RB(1, sB1, 0), NOP_, RB(1, sB1, 1), NOP_, RB(1, sB1, 2), NOP_, RB(1, sB1, 3), NOP_,  \
-       IS(9), NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);                                                \
-    LANDED(NH * t + 9 < htot, 8);                                                                       \
-    PH(0, 1, ab, 1, RA(1 - ab, sA, 0), RA(1 - ab, sA, 1), RA(1 - ab, sA, 2), RA(1 - ab, sA, 3),         \
-       RA(1 - ab, sA, 4), RA(1 - ab, sA, 5), RA(1 - ab, sA, 6), RA(1 - ab, sA, 7),                      \
-       RB(0, sB0, 0), RB(0, sB0, 1), RB(0, sB0, 2), RB(0, sB0, 3), IS(10), NOP_, IS(11), NOP_);         \
-  } while (0)
-    // 256x256 (A0 B0 | B1 | A1 | -): ph1 reads B1(t), ph2 A1(t), ph4 A0(t+1), B0(t+1)
-#define STEP2(bb)                                                                                       \
-  do {                                                                                                  \
-    const int sB1 = ring_slot(rb + 2), sA1 = ring_slot(rb + 3), sA0 = ring_slot(rb + 4), sB0 = ring_slot(rb + 5); \
-    PH(0, 0, 0, bb, RB(1 - bb, sB1, 0), NOP_, RB(1 - bb, sB1, 1), NOP_, RB(1 - bb, sB1, 2), NOP_,        \
-       RB(1 - bb, sB1, 3), NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);                       \
-    PH(0, 1, 0, 1 - bb, RA(1, sA1, 0), RA(1, sA1, 1), RA(1, sA1, 2), RA(1, sA1, 3), RA(1, sA1, 4),      \
-       RA(1, sA1, 5), RA(1, sA1, 6), RA(1, sA1, 7), IS(10), NOP_, NOP_, IS(11), NOP_, NOP_, NOP_, NOP_); \
-    PH(1, 1, 1, 1 - bb, NOP_, NOP_, IS(12), NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, \
-       NOP_, NOP_, NOP_);                                                                               \
-    LANDED(NH * t + 12 < htot, 10);                                                                     \
-    PH(1, 0, 1, bb, RA(0, sA0, 0), RA(0, sA0, 1), RA(0, sA0, 2), RA(0, sA0, 3), RA(0, sA0, 4),          \
-       RA(0, sA0, 5), RA(0, sA0, 6), RA(0, sA0, 7), RB(1 - bb, sB0, 0), RB(1 - bb, sB0, 1),             \
-       RB(1 - bb, sB0, 2), RB(1 - bb, sB0, 3), IS(13), NOP_, NOP_, NOP_);                               \
-  } while (0)
-    // 128x384 (A B0 | B1 | B2): ph1 reads B1(t), ph2 B2(t), ph3 A(t+1), B0(t+1)
-#define STEP3(ab, bb)                                                                                   \
-  do {                                                                                                  \
-    const int sB1 = ring_slot(rb + 2), sB2 = ring_slot(rb + 3), sA = ring_slot(rb + 4), sB0 = ring_slot(rb + 5); \
-    PH(0, 0, ab, bb, RB(1 - bb, sB1, 0), NOP_, RB(1 - bb, sB1, 1), NOP_, RB(1 - bb, sB1, 2), NOP_,       \
-       RB(1 - bb, sB1, 3), NOP_, IS(9), NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);                      \
-    PH(0, 1, ab, 1 - bb, RB(bb, sB2, 0), NOP_, RB(bb, sB2, 1), NOP_, RB(bb, sB2, 2), NOP_,               \
-       RB(bb, sB2, 3), NOP_, IS(10), NOP_, NOP_, IS(11), NOP_, NOP_, NOP_, NOP_);                       \
-    LANDED(NH * t + 11 < htot, 8);                                                                      \
-    PH(0, 2, ab, bb, RA(1 - ab, sA, 0), RA(1 - ab, sA, 1), RA(1 - ab, sA, 2), RA(1 - ab, sA, 3),        \
-       RA(1 - ab, sA, 4), RA(1 - ab, sA, 5), RA(1 - ab, sA, 6), RA(1 - ab, sA, 7),                      \
-       RB(1 - bb, sB0, 0), RB(1 - bb, sB0, 1), RB(1 - bb, sB0, 2), RB(1 - bb, sB0, 3), IS(12), NOP_, NOP_, NOP_); \
-  } while (0)
-    while (true) {
-      if constexpr (V == 1) STEP1(0); else if constexpr (V == 2) STEP2(0); else STEP3(0, 0);
-      NEXT_T();
-      if (t >= nk) break;
-      if constexpr (V == 1) STEP1(1); else if constexpr (V == 2) STEP2(1); else STEP3(1, 1);
-      NEXT_T();
-      if (t >= nk) break;
-    }
-    BARRIER();
-#undef STEP1
-#undef STEP2
-#undef STEP3
-#undef NEXT_T
-#undef MF
-#undef RA
-#undef RB
-#undef IS
-#undef PH
-#undef NOP_
-  } else {
-  // Stagger: the second wave of every SIMD (waves 4-7 = wm 1) runs half a phase behind the first, so
-  // one group's LDS reads overlap the other group's MFMAs. A phase is {DMA issue, fragment reads,
-  // BARRIER, 16 MFMAs, BARRIER}; the late group executes one extra barrier here and the early group
-  // one after the loop. Consequences for the hand-offs (both checked against the half-phase skew):
-  //  - a vmcnt wait sits BEFORE the first barrier of the last phase and the data is first read in the
-  //    next phase 1: two barriers later for the early group, so the late group's wait has happened;
-  //  - BARRIER() retires the wave's own LDS reads (lgkmcnt(0)) first, so a slot read in phase P by the
-  //    late group is safe to re-fill by the early group's DMA in phase P+1.
-  if (wm == 1) BARRIER();
-
-  for (int t = 0; t < nk; ++t) {
-    if constexpr (V == 1) {         // 128x256: A B0 | B1
-      ISSUE(9);                     // slot of B1(t-1), read in the previous phase 2
-      READ_B(0, ring_slot(rb + 1));
-      READ_A(0, ring_slot(rb));
-      MFMA_PART(0, 0, 0);
-      ISSUE(10); ISSUE(11);         // slots of A(t), B0(t)
-      LANDED(NH * t + 11 < htot, 12);
-      READ_B(1, ring_slot(rb + 2));
-      MFMA_PART(0, 1, 1);
-    } else if constexpr (V == 2) {  // 256x256: A0 B0 | B1 | A1 | -
-      READ_B(0, ring_slot(rb + 1));
-      READ_A(0, ring_slot(rb));
-      MFMA_PART(0, 0, 0);
-      ISSUE(10); ISSUE(11);         // slots of A0(t), B0(t)
-      READ_B(1, ring_slot(rb + 2));
-      MFMA_PART(0, 1, 1);
-      ISSUE(12);                    // slot of B1(t)
-      READ_A(0, ring_slot(rb + 3));
-      MFMA_PART(1, 1, 1);
-      ISSUE(13);                    // slot of A1(t)
-      LANDED(NH * t + 13 < htot, 12);
-      MFMA_PART(1, 0, 0);
-    } else {                        // 128x384: A B0 | B1 | B2
-      ISSUE(9);                     // slot of B2(t-1)
-      READ_B(0, ring_slot(rb + 1));
-      READ_A(0, ring_slot(rb));
-      MFMA_PART(0, 0, 0);
-      ISSUE(10); ISSUE(11);         // slots of A(t), B0(t)
-      READ_B(1, ring_slot(rb + 2));
-      MFMA_PART(0, 1, 1);
-      ISSUE(12);                    // slot of B1(t)
-      LANDED(NH * t + 12 < htot, 10);
-      READ_B(0, ring_slot(rb + 3));
-      MFMA_PART(0, 2, 0);
-    }
-    rb += NH;
-    rb = rb >= RING ? rb - RING : rb;
-  }
-  if (wm == 0) BARRIER();
-  }
-#undef STAGE_I
-#undef ISSUE
-#undef STAGE_A
-#undef STAGE_B
-#undef READ_A
-#undef READ_B
-#undef MFMA_Q
-#undef MFMA_PART
-#undef PHASE
-#undef LANDED
-
-#if NT_DBG & 16
-  if (blockIdx.x == 17 && tid == 0) {
-    const unsigned long long dc = __builtin_readcyclecounter() - dbg_c0, dr = __builtin_amdgcn_s_memrealtime() - dbg_r0;
-    printf("K loop: %llu cycles in %llu ticks of 100 MHz -> %.0f MHz, %.3f us per K-tile\n", dc, dr,
-           (double)dc / ((double)dr / 100.0), (double)dr / 100.0 / nk);
-  }
-#endif
-  // ---- epilogue. Loads are batched per 16-row slab — all bias vectors once, then the residual / aux
-  // segments of one slab together — so a slab costs ONE memory round trip instead of one per 16x16
-  // tile. bf16 outputs leave through LDS: in MFMA layout one store instruction is 16 rows x 32 B, i.e. 16
-  // partial-line writes, and the write path of a CU retires those at a few clocks each (measured: 7 us
-  // of a 28 us 16384x768x768 launch, 19 of 79 us at N = 2304). The tile is packed into a padded LDS
-  // image (the ring is free now) and written out as full 128-B lines, 16 B per lane.
-  // Big-tile shapes have N % TN == 0; rows >= Mstore are computed but not stored.
-  constexpr int OROW = TN + 16;  // image row stride (elements): +32 B rotates the rows over the banks
-  static_assert(TM * OROW <= RING * HT, "output image must fit the ring");
-  f32x4 csum[NBH][2];  // column sums of this wave's rows (only when p.colpart is set)
-  float4 bz[NBH][2];
-#pragma unroll
-  for (int nh = 0; nh < NBH; ++nh)
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      csum[nh][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-      bz[nh][ni] = p.bias ? *(const float4*)(p.bias + bn * TN + nh * 128 + wn * 32 + ni * 16 + fq * 4)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  const int ncol0 = bn * TN + wn * 32 + fq * 4;
-  if constexpr (ACT == 3) {
-    // Fused GEMM + cross-entropy, pass 1: nothing is stored but, per row, the maximum and the sum of
-    // exp(logit - maximum) over this tile's real classes, and the logit of the row's target class when it lies in
-    // this tile. A row's 256 columns sit in 4 lanes (fq) of 4 waves (wn): shuffles, then a [row][wn] LDS table.
-    float* const stat = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int mh = 0; mh < NAH; ++mh)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) {
-        const int lrow = mh * 128 + wm * 64 + mi * 16 + frow;
-        const int m = bm * TM + lrow;
-        const int tg = (int)p.ce_tgt[m];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int nh = 0; nh < NBH; ++nh)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni) {
-            f32x4& v = acc[mh][mi][nh][ni];
-            const int n0 = ncol0 + nh * 128 + ni * 16;
-            v[0] += bz[nh][ni].x; v[1] += bz[nh][ni].y; v[2] += bz[nh][ni].z; v[3] += bz[nh][ni].w;
-            if ((unsigned)(tg - n0) < 4u) p.ce_tlogit[m] = v[tg - n0];
-            if (n0 + 3 >= p.ce_cols) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = (n0 + r < p.ce_cols) ? v[r] : -INFINITY;
-            }
-            mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-          }
-        float sm = 0.f;
-        if (mx > -INFINITY) {
-#pragma unroll
-          for (int nh = 0; nh < NBH; ++nh)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              const f32x4 v = acc[mh][mi][nh][ni];
-              sm += (__expf(v[0] - mx) + __expf(v[1] - mx)) + (__expf(v[2] - mx) + __expf(v[3] - mx));
-            }
-        }
-#pragma unroll
-        for (int o = 16; o < 64; o <<= 1) {  // merge the 4 lanes (fq) that hold the same row
-          const float m2 = __shfl_xor(mx, o, 64), s2 = __shfl_xor(sm, o, 64);
-          const float mm = fmaxf(mx, m2);
-          sm = mm > -INFINITY ? sm * __expf(mx - mm) + s2 * __expf(m2 - mm) : 0.f;
-          mx = mm;
-        }
-        if (fq == 0) { stat[(lrow * 4 + wn) * 2] = mx; stat[(lrow * 4 + wn) * 2 + 1] = sm; }
-      }
-    __syncthreads();
-    const int ntile = p.N / TN;
-    for (int r = tid; r < TM; r += 512) {
-      float mx = -INFINITY, sm = 0.f;
-#pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4) {
-        const float m2 = stat[(r * 4 + w4) * 2], s2 = stat[(r * 4 + w4) * 2 + 1];
-        const float mm = fmaxf(mx, m2);
-        sm = mm > -INFINITY ? sm * __expf(mx - mm) + s2 * __expf(m2 - mm) : 0.f;
-        mx = mm;
-      }
-      p.ce_pmax[(size_t)(bm * TM + r) * ntile + bn] = mx;
-      p.ce_psum[(size_t)(bm * TM + r) * ntile + bn] = sm;
-    }
-    return;
-  }
-  uint2 keep[NAH][4][NBH][2];  // ACT == 1: the packed pre-activations, for the second (gelu) image
-#pragma unroll
-  for (int mh = 0; mh < NAH; ++mh)
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int lrow = mh * 128 + wm * 64 + mi * 16 + frow;  // row inside the tile
-      const int m = bm * TM + lrow;
-      uint2 rr[NBH][2], ux[NBH][2];
-      if (p.res) {
-#pragma unroll
-        for (int nh = 0; nh < NBH; ++nh)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            rr[nh][ni] = *(const uint2*)(p.res + (size_t)m * p.ldr + ncol0 + nh * 128 + ni * 16);
-      }
-      if (ACT == 2) {
-#pragma unroll
-        for (int nh = 0; nh < NBH; ++nh)
-#pragma unroll
-          for (int ni = 0; ni < 2; ++ni)
-            ux[nh][ni] = *(const uint2*)(p.aux + (size_t)m * p.ldaux + ncol0 + nh * 128 + ni * 16);
-      }
-      const bool st = m < p.Mstore;
-      // ACT == 4, fused GEMM + cross-entropy pass 2: the logits are recomputed and leave as the gradient
-      // (softmax - onehot) * w, with the row's log-sum-exp from pass 1; padding columns and rows get 0 (w = 0)
-      float ce_l = 0.f, ce_wt = 0.f;
-      int ce_t = -1;
-      if (ACT == 4) { ce_l = p.ce_lse[m]; ce_wt = p.ce_w[m]; ce_t = (int)p.ce_tgt[m]; }
-#pragma unroll
-      for (int nh = 0; nh < NBH; ++nh)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          f32x4 v = acc[mh][mi][nh][ni];
-          const int n0 = ncol0 + nh * 128 + ni * 16;
-          v[0] += bz[nh][ni].x; v[1] += bz[nh][ni].y; v[2] += bz[nh][ni].z; v[3] += bz[nh][ni].w;
-          if (ACT == 4) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              // select, never 0 * exp(): rows without loss (w = 0: padding, positions past the length) hold live or
-              // stale hidden states whose logit could overflow the exponential
-              float gq = (ce_wt != 0.f && n0 + r < p.ce_cols) ? __expf(v[r] - ce_l) * ce_wt : 0.f;
-              gq -= (n0 + r == ce_t) ? ce_wt : 0.f;
-              v[r] = gq;
-            }
-          }
-          if (p.res) {
-            v[0] += bf_lo(rr[nh][ni].x); v[1] += bf_hi(rr[nh][ni].x);
-            v[2] += bf_lo(rr[nh][ni].y); v[3] += bf_hi(rr[nh][ni].y);
-          }
-          if (ACT == 2) {  // gelu backward: multiply by gelu_new'(u); exact zeros stay zeros whatever u holds
-            v[0] = v[0] != 0.f ? v[0] * gelu_new_grad_f(bf_lo(ux[nh][ni].x)) : 0.f;
-            v[1] = v[1] != 0.f ? v[1] * gelu_new_grad_f(bf_hi(ux[nh][ni].x)) : 0.f;
-            v[2] = v[2] != 0.f ? v[2] * gelu_new_grad_f(bf_lo(ux[nh][ni].y)) : 0.f;
-            v[3] = v[3] != 0.f ? v[3] * gelu_new_grad_f(bf_hi(ux[nh][ni].y)) : 0.f;
-          }
-          if (OUTF32) {
-            if (st) *(float4*)(p.Cf + (size_t)m * p.ldcf + n0) = make_float4(v[0], v[1], v[2], v[3]);
-          } else {
-            uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-            *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = o;
-            if (ACT == 1) keep[mh][mi][nh][ni] = o;
-            v = f32x4{bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};  // the values as stored
-          }
-          if (st) csum[nh][ni] += v;
-        }
-    }
-  if (!OUTF32) {
-    constexpr int CPR = TN / 8;  // 16-B chunks per tile row
-    bf16_t* const cbase = p.C + (size_t)(bm * TM) * p.ldc + bn * TN;
-    const int rows_ok = p.Mstore - bm * TM;  // rows of this tile that are stored
-    __syncthreads();
-#pragma unroll 4
-    for (int c = tid; c < TM * CPR; c += 512) {
-      const int r = c / CPR, cc = c - r * CPR;
-      const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
-      if (r < rows_ok) *(uint4*)(cbase + (size_t)r * p.ldc + cc * 8) = v;
-    }
-    if (ACT == 1) {  // gelu forward: C keeps the bf16 pre-activation u, C2 = gelu_new(u)
-      __syncthreads();
-#pragma unroll
-      for (int mh = 0; mh < NAH; ++mh)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-          for (int nh = 0; nh < NBH; ++nh)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-              const uint2 o = keep[mh][mi][nh][ni];
-              uint2 g;
-              g.x = pack_bf2(gelu_new_f(bf_lo(o.x)), gelu_new_f(bf_hi(o.x)));
-              g.y = pack_bf2(gelu_new_f(bf_lo(o.y)), gelu_new_f(bf_hi(o.y)));
-              *(uint2*)&smem[(mh * 128 + wm * 64 + mi * 16 + frow) * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = g;
-            }
-      __syncthreads();
-      bf16_t* const gbase = p.C2 + (size_t)(bm * TM) * p.ldc2 + bn * TN;
-#pragma unroll 4
-      for (int c = tid; c < TM * CPR; c += 512) {
-        const int r = c / CPR, cc = c - r * CPR;
-        const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
-        if (r < rows_ok) *(uint4*)(gbase + (size_t)r * p.ldc2 + cc * 8) = v;
-      }
-    }
-  }
-  if (p.colpart) {
-    // Bias gradient of the producing Linear for free: sum the stored values over this wave's 64*NAH rows
-    // (16 lanes hold 16 different rows of the same 4 columns) and write ONE partial row per (row tile, wm):
-    // colpart[(bm*2 + wm)][n]; a fixed-order column sum over these few rows finishes it (deterministic).
-#pragma unroll
-    for (int nh = 0; nh < NBH; ++nh)
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
-        f32x4 v = csum[nh][ni];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          v[0] += __shfl_xor(v[0], o, 64); v[1] += __shfl_xor(v[1], o, 64);
-          v[2] += __shfl_xor(v[2], o, 64); v[3] += __shfl_xor(v[3], o, 64);
-        }
-        if (frow == 0)
-          *(float4*)(p.colpart + (size_t)(bm * 2 + wm) * p.N + bn * TN + nh * 128 + wn * 32 + ni * 16 + fq * 4) =
-              make_float4(v[0], v[1], v[2], v[3]);
-      }
-  }
-}
 
 template <int V, bool PF>
 int launch_big(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {

@@ -37,7 +37,16 @@ typedef struct {
   float* ce_tlogit;             // act 3 out: [M] logit of the target class
   const float* ce_lse;          // act 4 in: [M] log-sum-exp of the row
   const float* ce_w;            // act 4 in: [M] row weight (0 on rows without loss)
+  // fp8 operand mode (plb_launch_gemm_nt_fp8, gemm_fp8.hip): A and B are 1-byte images (lda / ldb / K count elements)
+  const float* deq_a; const float* deq_b;  // device scalars: 1 / scale of each operand
+  uint8_t* C8; int ldc8;        // optional fp8 copy of the output that feeds the next fp8 GEMM (act 1: of C2 = gelu; else of C)
+  const float* q_scale;         // device scalar: C8 = saturate(value * q_scale[0])
+  float* q_amax;                // device scalar: atomic max of |value| over the launch (next step's scale)
+  int c8_bf8;                   // C8 format: 0 e4m3, 1 e5m2
 } PlbGemmNT;
+// fp8 (e4m3 weights; e4m3 or e5m2 activations / gradients) form of plb_launch_gemm_nt on the pipeline kernel.
+// Returns 3 when the shape has no big-tile form (the caller then uses the bf16 GEMM).
+int plb_launch_gemm_nt_fp8(const PlbGemmNT* p, int act, int a_bf8, hipStream_t stream);
 int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream);
 int plb_gemm_nt_colpart_rows(int M, int N, int K);  // rows of colpart written for this shape (0: unsupported)
 // Tuning / test hooks (not part of include/plbert.h): force a tile (0 = per-shape policy; 128, 256, 384, 1256 =
@@ -90,7 +99,16 @@ typedef struct {
   const bf16_t* dy; int lddy;
   bf16_t* dx; int lddx;
   float* partials; int nblocks;
+  // fp8 copy of the output for the fp8 GEMM that consumes it (H = 768 / 1024 kernels only): forward y8 = e4m3(y * s),
+  // backward dx8 = e5m2(dx * s); q_amax collects max |value| (the next step's scale); all NULL = off
+  uint8_t* out8; int ld8; const float* q_scale; float* q_amax;
 } PlbLayerNorm;
+// fp8 plumbing (rowops.hip): |x| maximum of a bf16 / fp32 buffer into a device scalar (atomic max; zero it first),
+// scale update (delayed scaling: scale = fmax / amax, deq = 1 / scale, amax reset), quantisation of a bf16 / fp32 matrix
+int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols, int ld, float* amax, hipStream_t stream);
+int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, hipStream_t stream);
+int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int cols, int ld, const float* scale, uint8_t* out, int ldo,
+                        int bf8, hipStream_t stream);
 int plb_launch_ln_fwd(const PlbLayerNorm* p, hipStream_t stream);
 int plb_launch_ln_bwd(const PlbLayerNorm* p, hipStream_t stream);
 
@@ -118,6 +136,7 @@ typedef struct {
   const bf16_t* dctx; int lddctx;
   float* delta;                 // [B,NH,S]
   bf16_t* dqkv; int lddqkv;     // [T,3H]
+  float* colpart;               // backward, optional: [B * ceil(S/128) * 4][3H] column sums of dqkv per (sample, 128-row tile, wave)
 } PlbAttn;
 int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream);
 int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream);  // dq (+delta) then dk,dv

@@ -197,6 +197,17 @@ class HipEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.L.plb_allreduce_grads(self.handle, self._stream()), "plb_allreduce_grads")
 
+    def set_fp8(self, on=True):
+        """fp8 (e4m3 / e5m2) MFMA path for the QKV / FFN GEMMs (plb_set_fp8); the next call calibrates in bf16."""
+        self._bind()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.plb_set_fp8(self.handle, int(bool(on)), self._stream()), "plb_set_fp8")
+
+    def fp8_state(self):
+        a, b = C.c_int32(), C.c_int32()
+        _lib.check(self.L.plb_fp8_state(self.handle, C.byref(a), C.byref(b)), "plb_fp8_state")
+        return bool(a.value), bool(b.value)
+
     @property
     def token_head_steps(self):
         return int(self.L.plb_token_head_steps(self.handle))

@@ -181,7 +181,7 @@ def test_dual_head_optimizer_state_round_trips_and_keeps_its_own_step():
         opt.zero_grad()
         loss.backward()
         opt.step()
-        return float(loss)
+        return float(loss.detach())
 
     m, opt = make()
     step(m, opt, b3); step(m, opt, b3)            # two phoneme-only steps: the token head has no state yet

@@ -9,6 +9,6 @@ mkdir -p $P/build/dbg
 for n in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DNT_DBG=$n -x hip -c $P/csrc/gemm_big.hip -o $P/build/dbg/gemm_big_$n.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o $P/build/dbg/libplbert_dbg$n.so \
-    $P/build/gemm.o $P/build/dbg/gemm_big_$n.o $P/build/attn.o $P/build/rowops.o $P/build/mask.o $P/build/engine.o
+    $P/build/gemm.o $P/build/gemm_fp8.o $P/build/dbg/gemm_big_$n.o $P/build/attn.o $P/build/rowops.o $P/build/mask.o $P/build/engine.o
   echo built $P/build/dbg/libplbert_dbg$n.so
 done
