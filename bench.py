@@ -131,7 +131,7 @@ def cpu_baseline(budget_s):
 def _in_class(cls, name):
     import re
     if cls in ("gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32"):
-        m = re.search(r"gemm_nt_big_kernel<\d+, (\d+), (false|true), (?:false|true)>", name) or \
+        m = re.search(r"gemm_nt_big_kernel<\d+, (\d+), (false|true), (?:false|true)(?:, (?:false|true))*>", name) or \
             re.search(r"gemm_nt_kernel<(\d+), (false|true)>", name)
         if not m:
             return False

@@ -41,8 +41,17 @@ DEVI uint32_t pack_fp8x4(float a, float b, float c, float d, bool bf8) {
   else { v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false); v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true); }
   return (uint32_t)v;
 }
-// atomic max of a non-negative float (IEEE order == unsigned order for x >= 0)
-DEVI void atomic_max_abs(float* dst, float v) { atomicMax((unsigned int*)dst, __float_as_uint(v)); }
+// Running maximum of |x| of one fp8 site. Thousands of waves report per launch and same-address atomics retire at
+// ~12 ns each (MI355X_MICROARCH.md, fanin: 8192 of them = 100 us, measured as a 2x slower LayerNorm), so a site is
+// F8_SLOTS words on separate 64-byte lines and a wave reports into the slot its id selects: the atomics of a launch
+// spread over 64 lines and retire in parallel; plb_launch_fp8_scales takes the maximum over the slots.
+// IEEE order == unsigned order for x >= 0.
+constexpr int F8_SLOTS = 64, F8_STRIDE = 16;
+DEVI void atomic_max_abs(float* site, float v, unsigned int who) {
+  unsigned int* dst = (unsigned int*)site + (who & (F8_SLOTS - 1)) * F8_STRIDE;
+  const unsigned int bits = __float_as_uint(v);
+  if (bits > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, bits);
+}
 
 // gelu_new (HF activations.py:59-66): 0.5 x (1 + tanh(z)), z = sqrt(2/pi) (x + 0.044715 x^3)
 //   = x * sigmoid(2z) = x / (1 + exp2(x * (K1 + K3 x^2))),  K1 = -2 sqrt(2/pi) log2(e), K3 = 0.044715 K1.

@@ -381,7 +381,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
     e->o_w1T8 = cv.take(rup(H, 128) * I + 256 * I);
   }
   e->f8n = 5 * (int)L + 5;
-  e->o_f8amax = cv.take(e->f8n * 4); e->o_f8scale = cv.take(e->f8n * 4); e->o_f8deq = cv.take(e->f8n * 4);
+  e->o_f8amax = cv.take((int64_t)e->f8n * 64 * 16 * 4); e->o_f8scale = cv.take(e->f8n * 4); e->o_f8deq = cv.take(e->f8n * 4);
   e->ws_bytes = cv.off;
   *out = e;
   return 0;
@@ -443,10 +443,11 @@ extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_av
 // Sites: activations X (layer input), A (attention block output), G (gelu output) in e4m3; gradients DP (dpre2) and DU
 // in e5m2 (their range within a tensor is what e5m2's five exponent bits are for); weights W* in e4m3.
 enum { F8_X = 0, F8_A, F8_G, F8_DP, F8_DU, F8_NSITE };
+enum { F8_AMAX_WORDS = 64 * 16 };  // floats per site in the amax array (common.h: F8_SLOTS x F8_STRIDE)
 enum { F8W_QKV = 0, F8W_1, F8W_2, F8W_2T, F8W_1T };
 static int f8_site(const PlbEngine* e, int site, int l) { return site * e->L + l; }
 static int f8_w(const PlbEngine* e, int w) { return F8_NSITE * e->L + w; }
-static float* f8_amax(const PlbEngine* e, int i) { return e->at<float>(e->o_f8amax) + i; }
+static float* f8_amax(const PlbEngine* e, int i) { return e->at<float>(e->o_f8amax) + (int64_t)i * F8_AMAX_WORDS; }
 static float* f8_scale(const PlbEngine* e, int i) { return e->at<float>(e->o_f8scale) + i; }
 static float* f8_deq(const PlbEngine* e, int i) { return e->at<float>(e->o_f8deq) + i; }
 // every GEMM of the fp8 set has a pipeline-tile form at this token count (else the whole call runs in bf16)
@@ -465,7 +466,7 @@ static int fp8_quantize_weights(PlbEngine* e, hipStream_t s) {
       {F8W_2, e->par(PLB_FFNO_W), 0, H, I, e->o_w28},
       {F8W_2T, e->infer ? nullptr : e->at<bf16_t>(e->o_w2T), 1, I, H, e->o_w2T8},
       {F8W_1T, e->infer ? nullptr : e->at<bf16_t>(e->o_w1T), 1, H, I, e->o_w1T8}};
-  HIPTRY(hipMemsetAsync(f8_amax(e, f8_w(e, 0)), 0, 5 * sizeof(float), s));
+  HIPTRY(hipMemsetAsync(f8_amax(e, f8_w(e, 0)), 0, 5 * F8_AMAX_WORDS * sizeof(float), s));
   for (auto& w : ws) {
     if (!w.src) continue;
     TRY(plb_launch_amax(w.src, w.bf16, (size_t)w.rows, w.cols, w.cols, f8_amax(e, f8_w(e, w.w)), s));
@@ -520,7 +521,7 @@ extern "C" int plb_set_fp8(PlbEngine* e, int32_t on, void* stream) {
   if (on && !(e->H == 768 || e->H == 1024)) return fail("plb_set_fp8: the fp8 path needs hidden_size 768 or 1024");
   if (on && !e->fp8_on) {  // the first call afterwards runs in bf16 and calibrates the scales
     hipStream_t s = (hipStream_t)stream;
-    HIPTRY(hipMemsetAsync(f8_amax(e, 0), 0, (size_t)e->f8n * 4, s));
+    HIPTRY(hipMemsetAsync(f8_amax(e, 0), 0, (size_t)e->f8n * F8_AMAX_WORDS * 4, s));
     e->fp8_ready = false;      // activation sites: armed by the first forward
     e->fp8_bwd_ready = false;  // gradient sites: armed by the first backward
     e->fp8_wstale = true;

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
         }
         if (p.q_amax) {
           amax = wave_max(amax);
-          if (lane == 0) atomic_max_abs(p.q_amax, amax);
+          if (lane == 0) atomic_max_abs(p.q_amax, amax, blockIdx.x * 8 + uw);
         }
       }
     }

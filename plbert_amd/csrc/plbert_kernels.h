@@ -103,7 +103,9 @@ typedef struct {
   // backward dx8 = e5m2(dx * s); q_amax collects max |value| (the next step's scale); all NULL = off
   uint8_t* out8; int ld8; const float* q_scale; float* q_amax;
 } PlbLayerNorm;
-// fp8 plumbing (rowops.hip): |x| maximum of a bf16 / fp32 buffer into a device scalar (atomic max; zero it first),
+// fp8 plumbing (rowops.hip). An "amax" argument anywhere in this file is one SITE: 64 words on 64-byte lines (common.h:
+// F8_SLOTS x F8_STRIDE floats) that the waves of a launch spread their atomic maxima over; plb_launch_fp8_scales reduces
+// n consecutive sites. |x| maximum of a bf16 / fp32 buffer into a site (atomic max; zero it first),
 // scale update (delayed scaling: scale = fmax / amax, deq = 1 / scale, amax reset), quantisation of a bf16 / fp32 matrix
 int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols, int ld, float* amax, hipStream_t stream);
 int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, hipStream_t stream);

@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void ln_fwd_wide_kernel(PlbLayerNorm p) {
   }
   if (p.out8 && p.q_amax) {
     amax = wave_max(amax);
-    if (lane == 0) atomic_max_abs(p.q_amax, amax);
+    if (lane == 0) atomic_max_abs(p.q_amax, amax, blockIdx.x * 4 + wave);
   }
 }
 
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(PlbLayerNorm p) {
 #undef LNW_LOAD
   if (p.out8 && p.q_amax) {
     amax = wave_max(amax);
-    if (lane == 0) atomic_max_abs(p.q_amax, amax);
+    if (lane == 0) atomic_max_abs(p.q_amax, amax, blockIdx.x * 4 + wave);
   }
   // padding rows of the token dimension: keep them zero so they add nothing to the batched dW GEMMs
   for (int t = p.T + blockIdx.x * 4 + wave; t < p.Tzero; t += gridDim.x * 4)
@@ -840,20 +840,21 @@ __global__ __launch_bounds__(256) void amax_kernel(const void* X, size_t rows, i
     }
   }
   m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) atomic_max_abs(out, m);
+  if ((threadIdx.x & 63) == 0) atomic_max_abs(out, m, blockIdx.x * 4 + (threadIdx.x >> 6));
 }
 // Delayed scaling: the scale a tensor is quantised with in the NEXT step is fmax / (the maximum seen in this one);
 // a site that saw nothing (amax 0) keeps its scale. deq = 1 / scale is what the GEMM epilogues multiply by.
-__global__ void fp8_scales_kernel(float* amax, float* scale, float* deq, int n, float fmax) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per site: maximum over the site's F8_SLOTS words, then the update, then the words are cleared.
+__global__ __launch_bounds__(64) void fp8_scales_kernel(float* amax, float* scale, float* deq, int n, float fmax) {
+  const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= n) return;
-  const float a = amax[i];
-  if (a > 0.f && a < INFINITY) {
-    const float s = fmax / a;
-    scale[i] = s;
+  float* w = amax + (size_t)i * F8_SLOTS * F8_STRIDE + lane * F8_STRIDE;
+  const float a = wave_max(w[0]);
+  w[0] = 0.f;
+  if (lane == 0 && a > 0.f && a < INFINITY) {
+    scale[i] = fmax / a;
     deq[i] = a / fmax;
   }
-  amax[i] = 0.f;
 }
 // out[r][c] = fp8(x[r][c] * scale): 8 elements per thread
 template <bool BF16>
@@ -1084,7 +1085,7 @@ extern "C" int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols
 }
 extern "C" int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, hipStream_t stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(fp8_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, amax, scale, deq, n, fmax);
+  hipLaunchKernelGGL(fp8_scales_kernel, dim3(n), dim3(64), 0, stream, amax, scale, deq, n, fmax);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int cols, int ld, const float* scale,

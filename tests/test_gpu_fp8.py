@@ -51,7 +51,7 @@ def test_fp8_gemm_against_fp32_on_the_same_quantised_operands(M, N, K, act, bf8)
     C8 = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
     deq = torch.tensor([1.0 / sa, 1.0 / sw], device=DEV)
     qs = torch.tensor([3.0], device=DEV)
-    amax = torch.zeros(1, device=DEV)
+    amax = torch.zeros(64 * 16, device=DEV)  # one site: 64 slots on separate 64-byte lines
     colp = torch.zeros(2 * (M // 128), N, device=DEV)
     p = _lib.PlbGemmNT()
     p.A, p.lda, p.B, p.ldb = A8.view(torch.uint8).data_ptr(), K, W8.view(torch.uint8).data_ptr(), K
@@ -81,7 +81,7 @@ def test_fp8_gemm_against_fp32_on_the_same_quantised_operands(M, N, K, act, bf8)
         assert rel_l2(C2[rows].float(), gl[rows]) < 4e-3
         q8 = C8.view(torch.float8_e4m3fn).float() / 3.0                     # the fp8 image of gelu as stored
         assert rel_l2(q8[rows], C2[rows].float()) < 4e-2                     # 3 mantissa bits
-        assert abs(float(amax) - float(C2[rows].float().abs().max())) < 1e-6
+        assert abs(float(amax.max()) - float(C2[rows].float().abs().max())) < 1e-6
     else:
         x = aux.float()
         k = 0.7978845608028654
