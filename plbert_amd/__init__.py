@@ -4,7 +4,7 @@ from .config import AlbertConfig, albert_config_from_yaml, load_config
 from .symbols import CharacterIndexer, symbols, PAD_ID, MASK_ID, SEPARATOR_ID, UNKNOWN_ID
 from .init import param_shapes, deterministic_state_dict, reference_init_state_dict
 from .data import (MaskedPhonemeDataset, PhonemeOnlyCollater, Collater, build_dataloader,
-                   length_to_mask, masked_indices_to_csr, synthetic_batch, seed_reference_streams, collate_decisions)
+                   length_to_mask, masked_indices_to_csr, synthetic_batch, seed_reference_streams, collate_decisions, seed_worker, DecisionsDataset)
 
 
 
@@ -21,6 +21,9 @@ def __getattr__(name):
     if name in ("save_checkpoint", "load_checkpoint", "find_latest_checkpoint"):
         from . import checkpoint
         return getattr(checkpoint, name)
+    if name == "DeviceFeeder":
+        from .pipeline import DeviceFeeder
+        return DeviceFeeder
     if name == "HipEngine":
         from .engine import HipEngine
         return HipEngine
@@ -34,5 +37,5 @@ __all__ = [
     "CharacterIndexer", "symbols", "PAD_ID", "MASK_ID", "SEPARATOR_ID", "UNKNOWN_ID",
     "param_shapes", "deterministic_state_dict", "reference_init_state_dict",
     "MaskedPhonemeDataset", "PhonemeOnlyCollater", "Collater", "build_dataloader",
-    "length_to_mask", "masked_indices_to_csr", "synthetic_batch", "seed_reference_streams", "collate_decisions",
+    "length_to_mask", "masked_indices_to_csr", "synthetic_batch", "seed_reference_streams", "collate_decisions", "seed_worker", "DecisionsDataset", "DeviceFeeder",
 ]

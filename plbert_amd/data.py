@@ -200,8 +200,40 @@ class Collater:
         return tokens, labels, masked, lengths, indices
 
 
-def build_dataloader(df, batch_size, device, dataset_config, use_token_ids, num_workers=0, **kwargs):
-    """95/5 train/val split by ``random.shuffle`` then two DataLoaders (dataloader.py:225-274)."""
+def seed_worker(worker_id):
+    """``worker_init_fn`` of a multi-worker DataLoader over MaskedPhonemeDataset. The masking draws from NumPy's and
+    Python's GLOBAL generators (dataloader.py:85-94); forked workers all inherit the parent's NumPy state, so without
+    this every worker would draw the SAME masks for its samples. torch gives each worker the seed
+    ``base_seed + worker_id`` (and seeds ``random`` and ``torch`` with it, not NumPy): both streams of the masking are
+    re-seeded from it here, so a run is reproducible given (torch seed, num_workers) and workers are independent.
+    With ``num_workers=0`` nothing is re-seeded: the stream is the reference's, bit for bit (tests/golden/masking.npz)."""
+    info = torch.utils.data.get_worker_info()
+    seed = (info.seed if info is not None else torch.initial_seed()) % (2 ** 32)
+    np.random.seed(seed)
+    random.seed(seed)
+
+
+class DecisionsDataset(torch.utils.data.Dataset):
+    """View of a MaskedPhonemeDataset whose items are ``decisions(i)`` records — the random draws only — for the
+    device-side application of the masking (plb_apply_mask): the host workers do the RNG and the char indexing, the GPU
+    the cropping, substitution, index lists and padding."""
+
+    def __init__(self, dataset):
+        self.dataset = dataset
+
+    def __len__(self):
+        return len(self.dataset)
+
+    def __getitem__(self, idx):
+        return self.dataset.decisions(idx)
+
+
+def build_dataloader(df, batch_size, device, dataset_config, use_token_ids, num_workers=0, decisions=False, **kwargs):
+    """95/5 train/val split by ``random.shuffle`` then two DataLoaders (dataloader.py:225-274).
+    ``num_workers > 0`` (the reference runs 0, train.py:253 — the single-threaded Python masking is its input
+    bottleneck): worker processes with independent, reproducible masking streams (``seed_worker``).
+    ``decisions=True``: batches are ``collate_decisions`` dicts for ``plbert_amd.pipeline.DeviceFeeder`` /
+    ``device_apply_mask`` instead of collated tensors."""
     from torch.utils.data import DataLoader, Subset
 
     dataset = MaskedPhonemeDataset(df, use_token_ids=use_token_ids, **dataset_config)
@@ -213,6 +245,13 @@ def build_dataloader(df, batch_size, device, dataset_config, use_token_ids, num_
     val_set = Subset(dataset, order[total - val_size:])
     collate = Collater() if use_token_ids else PhonemeOnlyCollater()
     pin = device != "cpu"
+    if decisions:
+        train_set = Subset(DecisionsDataset(dataset), order[: total - val_size])
+        val_set = Subset(DecisionsDataset(dataset), order[total - val_size:])
+        collate, pin = collate_decisions, False
+    if num_workers > 0:
+        kwargs.setdefault("worker_init_fn", seed_worker)
+        kwargs.setdefault("persistent_workers", True)
     train_loader = DataLoader(train_set, batch_size=batch_size, shuffle=True, drop_last=True,
                               collate_fn=collate, pin_memory=pin, num_workers=num_workers, **kwargs)
     val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, drop_last=False,

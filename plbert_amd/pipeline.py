@@ -1,0 +1,191 @@
+"""Host -> device input pipeline of the hot path (second half).
+
+The reference feeds its step from ``DataLoader(num_workers=0)`` (train.py:253): Python string masking on the training
+process's own thread, then synchronous ``.to(device)`` copies. ``DeviceFeeder`` keeps the GPU fed instead:
+
+  worker processes (``build_dataloader(num_workers=N)``: independent masking streams, data.seed_worker)
+    -> a producer thread packs every collated batch into ONE pinned host buffer
+    -> ONE asynchronous copy on a copy stream into one of ``depth`` device slots (the copy of batch i+1 runs beside
+       the step of batch i)
+    -> the step's stream waits for the slot's event only; a slot is reused once the step that read it has been enqueued
+       and its completion event recorded.
+
+Two batch forms: collated tensors of PhonemeOnlyCollater / Collater (``labels, masked, lengths, indices``), or
+``collate_decisions`` dicts, for which the cropping / substitution / index lists are produced on the GPU by
+plb_apply_mask (bit-exact with the host path, tests/test_gpu_apply_mask.py)."""
+from __future__ import annotations
+
+import queue
+import threading
+
+import numpy as np
+import torch
+
+from .data import masked_indices_to_csr
+from .train import StagedBatch, validate_batch
+
+
+def _pack(arrays):
+    """[(name, ndarray)] -> (uint8 array, {name: (offset, dtype, shape)}) with 16-byte aligned segments."""
+    meta, off = {}, 0
+    for name, a in arrays:
+        a = np.ascontiguousarray(a)
+        meta[name] = (off, a.dtype, a.shape)
+        off += (a.nbytes + 15) // 16 * 16
+    buf = np.empty(max(off, 16), dtype=np.uint8)
+    for name, a in arrays:
+        o = meta[name][0]
+        a = np.ascontiguousarray(a)
+        buf[o:o + a.nbytes] = a.view(np.uint8).ravel()
+    return buf, meta
+
+
+_TORCH_DT = {np.dtype("int64"): torch.int64, np.dtype("int32"): torch.int32, np.dtype("int8"): torch.int8}
+
+
+class DeviceFeeder:
+    """Iterate a DataLoader as device-resident ``StagedBatch`` objects, copies overlapped with compute.
+
+    ``for batch in DeviceFeeder(loader, device): trainer.step(batch)``. Call ``release(batch)`` after enqueuing the
+    work that reads a batch if you hold more than one batch at a time; plain iteration releases the previous batch
+    when the next one is requested."""
+
+    def __init__(self, loader, device=None, depth=2, vocab_size=None, validate=True, word_separator=None, prefetch=4):
+        self.loader = loader
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.depth = max(2, int(depth))
+        self.vocab_size, self.validate, self.word_separator = vocab_size, validate, word_separator
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.prefetch = prefetch
+        self._slots = [None] * self.depth          # device uint8 buffers
+        self._pinned = [None] * self.depth
+        self._ready = [torch.cuda.Event() for _ in range(self.depth)]
+        self._free = [torch.cuda.Event() for _ in range(self.depth)]
+        self._prev = None
+
+    # ---- producer thread: DataLoader -> packed host arrays -------------------------------------------------
+    def _produce(self, q):
+        try:
+            for item in self.loader:
+                q.put(self._host_pack(item))
+            q.put(None)
+        except BaseException as ex:  # surfaced in the consumer
+            q.put(ex)
+
+    def _host_pack(self, item):
+        if isinstance(item, dict):  # collate_decisions
+            arrs = [(k, item[k]) for k in ("ids", "repl", "sample_off", "word_off", "word_begin", "word_len", "action",
+                                           "crop_start")]
+            if item["word_token"] is not None:
+                arrs.append(("word_token", item["word_token"]))
+            buf, meta = _pack(arrs)
+            return ("decisions", buf, meta, dict(B=item["B"], S=item["S"], lengths=item["lengths"]))
+        token_ids = None
+        if len(item) == 5:
+            token_ids, *item = item
+        labels, masked, lengths, idx = item
+        labels, masked = np.asarray(labels), np.asarray(masked)
+        if self.validate and self.vocab_size:
+            validate_batch(labels, masked, lengths, idx, self.vocab_size)
+        off, flat = masked_indices_to_csr(idx)
+        arrs = [("labels", labels.astype(np.int64)), ("masked", masked.astype(np.int64)), ("offsets", off), ("flat", flat),
+                ("lengths", np.asarray(lengths, dtype=np.int32))]
+        if token_ids is not None:
+            arrs.append(("token_ids", np.asarray(token_ids).astype(np.int64)))
+        buf, meta = _pack(arrs)
+        return ("collated", buf, meta, dict(B=labels.shape[0], S=labels.shape[1], lengths=[int(x) for x in lengths],
+                                            n_masked=int(off[-1])))
+
+    # ---- consumer side --------------------------------------------------------------------------------------
+    def _view(self, dev, meta, name):
+        o, dt, shape = meta[name]
+        n = int(np.prod(shape)) * np.dtype(dt).itemsize
+        return dev[o:o + n].view(_TORCH_DT[np.dtype(dt)]).view(*shape) if n else torch.empty(shape, dtype=_TORCH_DT[np.dtype(dt)], device=self.device)
+
+    def _upload(self, k, buf):
+        n = buf.nbytes
+        if self._pinned[k] is None or self._pinned[k].numel() < n:
+            cap = max(n * 2, 1 << 16)
+            self._pinned[k] = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            self._slots[k] = torch.empty(cap, dtype=torch.uint8, device=self.device)
+        self._free[k].synchronize()                 # the step that last read this slot (and its pinned twin) is done
+        self._pinned[k][:n].numpy()[:] = buf
+        with torch.cuda.stream(self.copy_stream):
+            self._slots[k][:n].copy_(self._pinned[k][:n], non_blocking=True)
+            self._ready[k].record(self.copy_stream)
+        return self._slots[k]
+
+    def release(self, batch):
+        k = getattr(batch, "_slot", None)
+        if k is not None:
+            self._free[k].record(torch.cuda.current_stream(self.device))
+            batch._slot = None
+
+    def __iter__(self):
+        q = queue.Queue(maxsize=self.prefetch)
+        th = threading.Thread(target=self._produce, args=(q,), daemon=True)
+        th.start()
+        for k in range(self.depth):
+            self._free[k].record(torch.cuda.current_stream(self.device))
+        pending = []                                # uploaded, not yet yielded: (slot, kind, meta, info)
+        i, done = 0, False
+        with torch.cuda.device(self.device):
+            while True:
+                while not done and len(pending) < self.depth - 1:
+                    item = q.get()
+                    if item is None:
+                        done = True
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    kind, buf, meta, info = item
+                    k = i % self.depth
+                    i += 1
+                    pending.append((k, kind, meta, info, self._upload(k, buf)))
+                if not pending:
+                    break
+                if self._prev is not None:
+                    self.release(self._prev)
+                k, kind, meta, info, dev = pending.pop(0)
+                torch.cuda.current_stream(self.device).wait_event(self._ready[k])
+                batch = self._stage(kind, meta, info, dev)
+                batch._slot = k
+                self._prev = batch
+                yield batch
+        if self._prev is not None:
+            self.release(self._prev)
+            self._prev = None
+        th.join(timeout=5)
+
+    def _stage(self, kind, meta, info, dev):
+        B, S, lengths = info["B"], info["S"], info["lengths"]
+        if kind == "collated":
+            lens_t = None if all(x == S for x in lengths) else self._view(dev, meta, "lengths")
+            tok = self._view(dev, meta, "token_ids") if "token_ids" in meta else None
+            return StagedBatch(self._view(dev, meta, "masked"), self._view(dev, meta, "labels"), lens_t,
+                               self._view(dev, meta, "offsets"), self._view(dev, meta, "flat"), info["n_masked"],
+                               int(sum(lengths)), tok)
+        # decisions: the masking is applied on the device (plb_apply_mask)
+        import ctypes as C
+        from . import _lib
+        from .symbols import MASK_ID
+        L = _lib.lib()
+        v = lambda n: self._view(dev, meta, n)
+        wtok = v("word_token") if "word_token" in meta else None
+        labels = torch.empty((B, S), dtype=torch.int64, device=self.device)
+        masked = torch.empty_like(labels)
+        tokens = torch.empty_like(labels) if wtok is not None else None
+        lens = torch.empty(B, dtype=torch.int32, device=self.device)
+        offsets = torch.empty(B + 1, dtype=torch.int32, device=self.device)
+        flat = torch.empty(B * S, dtype=torch.int32, device=self.device)
+        scratch = torch.empty(B + B * S, dtype=torch.int32, device=self.device)
+        p = lambda t: None if t is None else t.data_ptr()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(L.plb_apply_mask(v("ids").data_ptr(), v("sample_off").data_ptr(), v("word_off").data_ptr(),
+                                    v("word_begin").data_ptr(), v("word_len").data_ptr(), v("action").data_ptr(),
+                                    v("repl").data_ptr(), p(wtok), int(self.word_separator or 0), v("crop_start").data_ptr(),
+                                    B, S, MASK_ID, labels.data_ptr(), masked.data_ptr(), p(tokens), lens.data_ptr(),
+                                    offsets.data_ptr(), flat.data_ptr(), scratch.data_ptr(), stream), "plb_apply_mask")
+        n = int(offsets[B].item())                  # the one host read of the path: the masked count sizes the loss GEMM
+        lens_t = None if all(x == S for x in lengths) else lens
+        return StagedBatch(masked, labels, lens_t, offsets, flat[:n], n, int(sum(lengths)), tokens)

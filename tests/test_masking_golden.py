@@ -101,3 +101,45 @@ def test_edge_cases():
     l, m, lens, ix = plbert_amd.synthetic_batch(4, 64, seed=5)
     assert l.shape == (4, 64) and all(len(i) > 0 for i in ix) and lens == [64] * 4
     assert ((l != m).sum(1) > 0).all() and (m[l == 186] == 186).all()
+
+
+def test_multi_worker_streams_are_independent_and_reproducible():
+    """N3: with num_workers > 0 every worker re-seeds BOTH masking streams from its torch worker seed (data.seed_worker).
+    Without that, forked workers share the parent's NumPy state and draw identical masks (the reference never runs
+    workers: train.py:253). Same (torch seed, num_workers) -> same batches; different workers -> different draws."""
+    docs = [{"phonemes": ["abcde", "fghij", "klmno", "pqrst"] * 30} for _ in range(64)]   # identical documents
+    cfg = dict(max_seq_length=128, **PARAMS)
+
+    def run(seed):
+        torch.manual_seed(seed)
+        pdata.seed_reference_streams(1)
+        tl, _ = plbert_amd.build_dataloader(docs, batch_size=4, device="cpu", dataset_config=cfg, use_token_ids=False,
+                                            num_workers=2)
+        out = []
+        for i, (lab, msk, lens, idx) in enumerate(tl):
+            out.append((msk.numpy().copy(), [list(x) for x in idx]))
+            if i == 3:
+                break
+        del tl
+        return out
+
+    a, b, c = run(7), run(7), run(8)
+    for (m1, i1), (m2, i2) in zip(a, b):
+        assert np.array_equal(m1, m2) and i1 == i2            # reproducible
+    assert any(not np.array_equal(m1, m2) for (m1, _), (m2, _) in zip(a, c))   # the torch seed drives the masks
+    # batches 0 and 1 come from workers 0 and 1: identical documents, so equal masks would mean a shared stream
+    assert not np.array_equal(a[0][0], a[1][0])
+    # within a batch, samples are not copies of each other either
+    assert len({tuple(r) for r in a[0][0].tolist()}) > 1
+
+
+def test_decisions_loader_collates_for_the_device_path():
+    g = load_golden("masking")
+    data = [{"phonemes": d} for d in _docs(g)] * 4
+    pdata.seed_reference_streams(1)
+    tl, vl = plbert_amd.build_dataloader(data, batch_size=4, device="cpu", dataset_config=dict(max_seq_length=64, **PARAMS),
+                                         use_token_ids=False, decisions=True)
+    c = next(iter(tl))
+    assert set(c) >= {"ids", "repl", "sample_off", "word_off", "word_begin", "word_len", "action", "crop_start", "lengths"}
+    assert c["B"] == 4 and c["S"] == max(c["lengths"]) <= 64 and c["lengths"] == sorted(c["lengths"], reverse=True)
+    assert c["sample_off"][-1] == len(c["ids"]) == len(c["repl"]) and c["word_off"][-1] == len(c["action"])
