@@ -397,7 +397,7 @@ def main():
 
     # ---- the same K steps with a fresh batch staged every step (H2D inside the timed region) -------------------
     staged = None
-    if not args.no_staged and not args.num_tokens:
+    if not args.no_staged and not args.num_tokens and not shared:  # (ranks sharing a device: rehearsal of the launch only)
         feeder = StagedFeeder(trainer, min(args.steps, 16), B, S, 99 + rank, torch)
         feeder.run(2)
         dts, _ = timed(feeder.run, args.steps)

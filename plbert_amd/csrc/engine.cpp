@@ -959,9 +959,9 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
 
 // Tail of the backward on two streams.
 //  main: the four large token-major weight-gradient GEMMs (MFMA-bound, ~2 ms at config A), each followed — when a
-//        communicator is attached — by the all-reduce of the contiguous piece of the flat gradient buffer it completed,
-//        on the communication stream: piece i travels over xGMI while GEMM i+1 runs. The smallest GEMM goes last, so
-//        only dense.weight's piece (2.4 MB of 23.4) has nothing left to hide behind.
+//        communicator is attached — by the all-reduce of the weight it completed, on the communication stream: weight i
+//        travels over xGMI while GEMM i+1 runs. The smallest GEMM goes last, so only dense.weight and the small
+//        tensors (3.2 MB of 23.4) have nothing left to hide behind.
 //  side: everything else that only needs finished gradients — embedding chain, bias and LayerNorm-affine column sums
 //        (HBM-bound) — with its own slab / scratch so nothing is shared; joined before the first piece that holds
 //        any of its outputs.
@@ -1012,18 +1012,24 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   TRY(plb_launch_copy_cols(scratch2, 16, 3 * H, 2 * H, H, e->grd(PLB_FFNO_B), s2));
   if (s2 != s) HIPTRY(hipEventRecord(e->ev_join, s2));
   // main stream: shared-layer weight gradients, one token-major GEMM per weight over all L applications ------------
+  // Overlapped exchange: a weight's range travels as soon as its GEMM (+ slab reduction) has written it. The small
+  // tensors between the weights in the flat order (biases, LayerNorm, embeddings) come from the side stream, which needs
+  // about as long as the first three GEMMs: they go last, behind the join, so the main stream never waits for it early.
   const bool ov = overlapping(e);
   if (weight_grad(e, e->at<bf16_t>(e->o_dqkv), 3 * H, 3 * H, e->at<bf16_t>(e->o_x), H, Mtot, 3 * H, H, e->grd(PLB_Q_W), s)) return 1;
-  if (ov) {  // [0, dense.weight): embeddings, map-in, LN2, QKV weights and biases — the side stream's share must be in
-    if (s2 != s) HIPTRY(hipStreamWaitEvent(s, e->ev_join, 0));
-    if (reduce_piece(e, 0, e->poff[PLB_DENSE_W], s)) return 1;
-  }
+  if (ov && reduce_piece(e, e->poff[PLB_Q_W], e->poff[PLB_Q_B], s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
-  if (ov && reduce_piece(e, e->poff[PLB_FFN_W], e->poff[PLB_FFNO_W], s)) return 1;
+  if (ov && reduce_piece(e, e->poff[PLB_FFN_W], e->poff[PLB_FFN_B], s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
-  if (ov && reduce_piece(e, e->poff[PLB_FFNO_W], e->poff[PLB_HEAD_W], s)) return 1;
+  if (ov && reduce_piece(e, e->poff[PLB_FFNO_W], e->poff[PLB_FFNO_B], s)) return 1;
   if (weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
-  if (ov && reduce_piece(e, e->poff[PLB_DENSE_W], e->poff[PLB_FFN_W], s)) return 1;
+  if (ov) {
+    if (s2 != s) HIPTRY(hipStreamWaitEvent(s, e->ev_join, 0));
+    if (reduce_piece(e, 0, e->poff[PLB_Q_W], s)) return 1;                    // embeddings, map-in, LN2
+    if (reduce_piece(e, e->poff[PLB_Q_B], e->poff[PLB_FFN_W], s)) return 1;  // QKV biases, dense (the smallest weight), LN1
+    if (reduce_piece(e, e->poff[PLB_FFN_B], e->poff[PLB_FFNO_W], s)) return 1;
+    if (reduce_piece(e, e->poff[PLB_FFNO_B], e->poff[PLB_HEAD_W], s)) return 1;
+  }
   return 0;
 }
 
