@@ -42,13 +42,17 @@ DEVI bf16x8 row_frag(const bf16_t* tile, int rb, int ks, int lane) {
   return *(const bf16x8*)&tile[row_off(row, ks * 2 + (lane >> 5))];
 }
 // registers 8s..8s+7 of a 32x32 accumulator -> bf16x8 operand fragment (k-step s)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 DEVI bf16x8 acc_frag(const f32x16& x, int s) {
-  bf16x8 r;
-  uint32_t u0 = pack_bf2(x[8 * s + 0], x[8 * s + 1]), u1 = pack_bf2(x[8 * s + 2], x[8 * s + 3]);
-  uint32_t u2 = pack_bf2(x[8 * s + 4], x[8 * s + 5]), u3 = pack_bf2(x[8 * s + 6], x[8 * s + 7]);
-  r[0] = (short)(u0 & 0xFFFF); r[1] = (short)(u0 >> 16); r[2] = (short)(u1 & 0xFFFF); r[3] = (short)(u1 >> 16);
-  r[4] = (short)(u2 & 0xFFFF); r[5] = (short)(u2 >> 16); r[6] = (short)(u3 & 0xFFFF); r[7] = (short)(u3 >> 16);
-  return r;
+  const u32x4_t u = {pack_bf2(x[8 * s + 0], x[8 * s + 1]), pack_bf2(x[8 * s + 2], x[8 * s + 3]),
+                     pack_bf2(x[8 * s + 4], x[8 * s + 5]), pack_bf2(x[8 * s + 6], x[8 * s + 7])};
+  return __builtin_bit_cast(bf16x8, u);  // four packed registers ARE the fragment: no lane or byte shuffles
+}
+DEVI f32x16 splat16(float v) {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = v;
+  return z;
 }
 DEVI f32x16 zero16() {
   f32x16 z;
@@ -293,7 +297,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
     const bf16_t* sV = smem[cur][2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      f32x16 s = zero16(), dp = zero16();
+      // row constants as the initial accumulator: the query sits on the lane, so dP starts at -delta and the
+      // MFMA chain leaves dP - delta ready (one VALU less per score)
+      f32x16 s = zero16(), dp = splat16(-delta);
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb, ks, lane), qf[ks], s, 0, 0, 0);
@@ -310,7 +316,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -lse2));
-        s[r] = pr * (dp[r] - delta);   // dS^T (scale applied once at the end)
+        s[r] = pr * dp[r];   // dS^T = P (dP - delta); the scale is applied once at the end
       }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -409,39 +415,43 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
     const bool need_mask = (key0 + 32 > len) || (qt * 64 + 64 > len);  // wave-uniform
     const bf16_t* sDO = smem[cur][2];
     const bf16_t* sDOt = smem[cur][3];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      f32x16 s = zero16(), dp = zero16();
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, qb, ks, lane), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sDO, qb, ks, lane), vf[ks], dp, 0, 0, 0);
-      }
-      // s[r] = S[q][key]: key on the lane, q = qt*64 + qb*32 + (r&3) + 8(r>>2) + 4h; dS overwrites dP
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int ql = qb * 32 + 8 * rg + 4 * h;
-        const float4 l4 = *(const float4*)&sstat[cur][0][ql];
-        const float4 d4 = *(const float4*)&sstat[cur][1][ql];
-        const float lv[4] = {l4.x, l4.y, l4.z, l4.w}, dv[4] = {d4.x, d4.y, d4.z, d4.w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = 4 * rg + j;
-          float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -lv[j]));
-          if (need_mask) pr = (key_ok && (qt * 64 + ql + j < len)) ? pr : 0.f;
-          s[r] = pr;
-          dp[r] = pr * (dp[r] - dv[j]);
-        }
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 pb = acc_frag(s, s2), dsb = acc_frag(dp, s2);
-        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDOt, qb, s2, 0, lane), pb, dv0, 0, 0, 0);
-        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDOt, qb, s2, 1, lane), pb, dv1, 0, 0, 0);
-        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQt, qb, s2, 0, lane), dsb, dk0, 0, 0, 0);
-        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQt, qb, s2, 1, lane), dsb, dk1, 0, 0, 0);
-      }
-    }
+    // The tile body exists twice: tiles that cross the length (of keys or of queries) mask, all the others run
+    // without a single compare / select — written as one select on a wave-uniform flag, hipcc if-converted the mask
+    // into every tile (32 v_cmp + 32 v_cndmask + 66 scalar mask ops per tile of a VALU-bound loop).
+    // Row constants as initial accumulators: dP starts at -delta[q] (q runs over the registers here), so the MFMA
+    // chain leaves dP - delta.
+#define DKV_TILE(MASK)                                                                                          \
+  _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                                            \
+    f32x16 s = zero16(), dp;                                                                                    \
+    float lv[16];                                                                                               \
+    _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                                          \
+      const int ql = qb * 32 + 8 * rg + 4 * h;                                                                  \
+      const float4 l4 = *(const float4*)&sstat[cur][0][ql];                                                     \
+      const float4 d4 = *(const float4*)&sstat[cur][1][ql];                                                     \
+      lv[4 * rg + 0] = l4.x; lv[4 * rg + 1] = l4.y; lv[4 * rg + 2] = l4.z; lv[4 * rg + 3] = l4.w;               \
+      dp[4 * rg + 0] = -d4.x; dp[4 * rg + 1] = -d4.y; dp[4 * rg + 2] = -d4.z; dp[4 * rg + 3] = -d4.w;           \
+    }                                                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                          \
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, qb, ks, lane), kf[ks], s, 0, 0, 0);              \
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sDO, qb, ks, lane), vf[ks], dp, 0, 0, 0);           \
+    }                                                                                                           \
+    /* s[r] = S[q][key]: key on the lane, q = qt*64 + qb*32 + (r&3) + 8(r>>2) + 4h; dS overwrites dP */         \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                            \
+      float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -lv[r]));                                     \
+      if (MASK) pr = (key_ok && (qt * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < len)) ? pr : 0.f;         \
+      s[r] = pr;                                                                                                \
+      dp[r] = pr * dp[r];                                                                                       \
+    }                                                                                                           \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                          \
+      const bf16x8 pb = acc_frag(s, s2), dsb = acc_frag(dp, s2);                                                \
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDOt, qb, s2, 0, lane), pb, dv0, 0, 0, 0);          \
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDOt, qb, s2, 1, lane), pb, dv1, 0, 0, 0);          \
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQt, qb, s2, 0, lane), dsb, dk0, 0, 0, 0);          \
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQt, qb, s2, 1, lane), dsb, dk1, 0, 0, 0);          \
+    }                                                                                                           \
+  }
+    if (need_mask) { DKV_TILE(true) } else { DKV_TILE(false) }
+#undef DKV_TILE
     Q_STORE(cur ^ 1);
     __syncthreads();
   }

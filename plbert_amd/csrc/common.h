@@ -16,7 +16,14 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 DEVI float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 // plain cast: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
 DEVI bf16_t f2bf(float f) { __bf16 b = (__bf16)f; return __builtin_bit_cast(bf16_t, b); }
-DEVI uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two floats -> one register of two bf16: the vector conversion lowers to ONE v_cvt_pk_bf16_f32 (the scalar form
+// (uint)f2bf(lo) | f2bf(hi) << 16 cost two conversions and a v_perm in the attention loops)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+DEVI uint32_t pack_bf2(float lo, float hi) {
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 DEVI float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 DEVI float bf_hi(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
 

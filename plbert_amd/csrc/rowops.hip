@@ -163,6 +163,12 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(PlbEmbed p, int P) {
 #define LN_R_ROWS 2
 #endif
 constexpr int LN_R = LN_R_ROWS;
+// the backward keeps x, dy and three accumulator sets per lane: one row in flight per wave (more waves per SIMD)
+// measured 16.5 vs 18.7 us at 16384 x 768 (tools/ln_bench.py)
+#ifndef LN_RB_ROWS
+#define LN_RB_ROWS 1
+#endif
+constexpr int LN_RB = LN_RB_ROWS;
 #ifndef LN_WIDE
 #define LN_WIDE 1   // 16-byte kernels for H = 768 / 1024 (0: the 8-byte kernels for every width)
 #endif
@@ -243,11 +249,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) dg[i][j] = db[i][j] = dxs[i][j] = 0.f;
   }
-  for (int t0 = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * LN_R; t0 < p.T; t0 += gridDim.x * 4 * LN_R) {
-    uint2 ux[LN_R][NCH], ud[LN_R][NCH];
-    float mean[LN_R], rstd[LN_R];
+  for (int t0 = (xcd_remap(blockIdx.x, gridDim.x) * 4 + wave) * LN_RB; t0 < p.T; t0 += gridDim.x * 4 * LN_RB) {
+    uint2 ux[LN_RB][NCH], ud[LN_RB][NCH];
+    float mean[LN_RB], rstd[LN_RB];
 #pragma unroll
-    for (int r = 0; r < LN_R; ++r) {
+    for (int r = 0; r < LN_RB; ++r) {
       const int t = (t0 + r < p.T) ? t0 + r : p.T - 1;
       mean[r] = p.mean[t]; rstd[r] = p.rstd[t];
 #pragma unroll
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
       }
     }
 #pragma unroll
-    for (int r = 0; r < LN_R; ++r) {
+    for (int r = 0; r < LN_RB; ++r) {
       const int t = t0 + r;
       if (t >= p.T) continue;  // wave-uniform
       float xh[NCH][4], dxh[NCH][4];

@@ -150,7 +150,12 @@ def test_attention_fwd_bwd(B, S, NH, lens):
     torch.cuda.synchronize()
     ref = grad(dctx)
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
-        assert rel_l2(dqkv[:, sl].float(), ref[:, sl]) < 1.5e-2, name
+        if float(ref[:, sl].abs().max()) == 0.0:
+            # a single valid key: P = 1 and dP - delta = 0 mathematically; the kernels form it as (-delta + sum of
+            # products) in fp32, i.e. to rounding (1e-7 of the terms), not bit-exactly
+            assert float(dqkv[:, sl].float().abs().max()) < 1e-5, name
+        else:
+            assert rel_l2(dqkv[:, sl].float(), ref[:, sl]) < 1.5e-2, name
     if lens:  # padded keys get exactly zero dK, dV
         kpad = ~(torch.arange(S, device=DEV)[None, :] < lengths[:, None]).reshape(B * S)
         assert (dqkv[kpad][:, H:] == 0).all()
