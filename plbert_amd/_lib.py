@@ -98,7 +98,7 @@ class PlbAttn(C.Structure):
         ("B", C.c_int), ("S", C.c_int), ("NH", C.c_int), ("H", C.c_int), ("scale", C.c_float),
         ("ctx", C.c_void_p), ("ldctx", C.c_int), ("lse", C.c_void_p),
         ("dctx", C.c_void_p), ("lddctx", C.c_int), ("delta", C.c_void_p), ("dqkv", C.c_void_p), ("lddqkv", C.c_int),
-        ("colpart", C.c_void_p),
+        ("colpart", C.c_void_p), ("colpart_accumulate", C.c_int),
     ]
 
 
@@ -117,7 +117,7 @@ class PlbLayerNorm(C.Structure):
         ("y", C.c_void_p), ("ldy", C.c_int), ("mean", C.c_void_p), ("rstd", C.c_void_p),
         ("T", C.c_int), ("H", C.c_int), ("Tzero", C.c_int),
         ("dy", C.c_void_p), ("lddy", C.c_int), ("dx", C.c_void_p), ("lddx", C.c_int),
-        ("partials", C.c_void_p), ("nblocks", C.c_int),
+        ("partials", C.c_void_p), ("nblocks", C.c_int), ("accumulate", C.c_int),
         ("out8", C.c_void_p), ("ld8", C.c_int), ("q_scale", C.c_void_p), ("q_amax", C.c_void_p),
     ]
 

@@ -67,7 +67,7 @@ DEVI f32x16 zero16() {
 // column c of the patch. The engine adds these few partial rows up into the Q/K/V bias gradient instead of re-reading
 // the stacked [L*T, 3H] gradient (906 MB per step at config A).
 DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_t* patch, bf16_t* gout, int ldo,
-                           int rows_valid, int lane, float* colsum = nullptr) {
+                           int rows_valid, int lane, float* colsum = nullptr, bool accumulate = false) {
   constexpr int PS = 72;  // elements per patch row (144 B)
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -93,7 +93,7 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
     float sacc = 0.f;
 #pragma unroll 8
     for (int rr = 0; rr < 32; ++rr) sacc += (rr < rows_valid) ? bf2f(patch[rr * PS + lane]) : 0.f;
-    colsum[lane] = sacc;
+    colsum[lane] = accumulate ? colsum[lane] + sacc : sacc;
   }
 }
 
@@ -335,8 +335,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
   // bias-gradient partial row of this wave: [(b * QT + q tile) * 4 + wave][3H], columns hd*64.. of the Q block
   float* cp = p.colpart ? p.colpart + ((size_t)(b * QT + bx) * 4 + wave) * (3 * H) + hd * 64 : nullptr;
   if (rows_valid > 0)
-    store_transposed(dq0, dq1, p.scale, patch, p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64, p.lddqkv, rows_valid, lane, cp);
-  else if (cp) cp[lane] = 0.f;
+    store_transposed(dq0, dq1, p.scale, patch, p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64, p.lddqkv, rows_valid, lane, cp,
+                     p.colpart_accumulate != 0);
+  else if (cp && !p.colpart_accumulate) cp[lane] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------- backward dK,dV
@@ -462,10 +463,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   float* cp = p.colpart ? p.colpart + ((size_t)(b * QT + bx) * 4 + wave) * (3 * H) + hd * 64 : nullptr;
   if (rows_valid > 0) {
     bf16_t* out = p.dqkv + (tok0 + key0) * p.lddqkv + hd * 64;
-    store_transposed(dk0, dk1, p.scale, patch, out + H, p.lddqkv, rows_valid, lane, cp ? cp + H : nullptr);
+    const bool accq = p.colpart_accumulate != 0;
+    store_transposed(dk0, dk1, p.scale, patch, out + H, p.lddqkv, rows_valid, lane, cp ? cp + H : nullptr, accq);
     __builtin_amdgcn_wave_barrier();
-    store_transposed(dv0, dv1, 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane, cp ? cp + 2 * H : nullptr);
-  } else if (cp) {
+    store_transposed(dv0, dv1, 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane, cp ? cp + 2 * H : nullptr, accq);
+  } else if (cp && !p.colpart_accumulate) {
     cp[H + lane] = 0.f;
     cp[2 * H + lane] = 0.f;
   }

@@ -228,14 +228,24 @@ static void layout_params(PlbEngine* e) {
 // Row splits of a token-major weight-gradient GEMM. Shapes that fit the 256x256 pipeline kernel get
 // one workgroup per CU (tiles x splits <= 256); the rest use the 128x128 kernel at ~3 workgroups per CU.
 static bool tn_big(int64_t Mtot, int Ncols, int K) { return Ncols % 256 == 0 && K % 256 == 0 && Mtot >= 8192; }
+// PLBERT_TN_SPLITS=xcd restores round 1's rule (8 * s splits, s * tiles <= 32: whole splits per XCD, but only 192-216
+// of the 256 CUs busy on the model's shapes); default: as many splits as fit one workgroup per CU.
+static bool tn_fill_chip() {
+  static const bool v = [] { const char* e = getenv("PLBERT_TN_SPLITS"); return !(e && !strcmp(e, "xcd")); }();
+  return v;
+}
 static int tn_splits(int64_t Mtot, int N, int K, int* rows_per_split) {
   const bool big = tn_big(Mtot, N, K);
   const int tiles = big ? (N / 256) * (K / 256) : ((N + 127) / 128) * ((K + 127) / 128);
   int splits = 768 / tiles;
-  if (big) {  // one split group per XCD: 8 * s splits with s * tiles <= 32 CUs of an XCD
+  if (big) {
+    // One workgroup per CU (128 KiB of LDS each): tiles * splits <= 256 and as close to it as the tile count allows —
+    // 24 tiles (the two FFN weights) -> 10 splits = 240 workgroups, 27 (QKV) -> 9 = 243, 9 (dense) -> 28 = 252. The
+    // kernel deals the (split, tile) pairs to the XCDs in contiguous runs (xcd_remap), so an XCD still streams a
+    // contiguous range of token rows through its L2 (a split may straddle two XCDs).
     int s = 32 / tiles;
     if (s < 1) s = 1;
-    splits = tiles >= 256 ? 1 : 8 * s;  // a wide output (token head) fills the chip without row splits
+    splits = tiles >= 256 ? 1 : (tn_fill_chip() ? 256 / tiles : 8 * s);  // a wide output (token head) needs no row splits
   }
   const int64_t maxs = Mtot / 64;
   if (splits > maxs) splits = (int)maxs;
@@ -340,7 +350,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
     e->o_dxe = cv.take(Tp * E * 4);
     e->o_ducol = cv.take(L * (2 * Tp / 128) * I * 4);  // column-sum partials of dU from the GEMM epilogue
     e->qkvcol_rows = c.max_batch * ((c.max_seq + 127) / 128) * 4;
-    e->o_qkvcol = cv.take(L * (int64_t)e->qkvcol_rows * 3 * H * 4);  // ... of dQKV from the attention-backward stores
+    e->o_qkvcol = cv.take((int64_t)e->qkvcol_rows * 3 * H * 4);  // ... of dQKV from the attention-backward stores (summed over L)
     e->o_scratch = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);  // colsum partials: up to 512 row splits
     e->o_scratch2 = cv.take(512 * (3 * H > I ? 3 * H : I) * 4);
     {
@@ -939,7 +949,7 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     at.qkv = qkv; at.ldqkv = 3 * H; at.lengths = lengths; at.B = B; at.S = S; at.NH = e->NH; at.H = H; at.scale = 0.125f;
     at.ctx = ctx; at.ldctx = H; at.lse = e->at<float>(e->o_lse) + (int64_t)l * B * e->NH * S;
     at.dctx = dctx; at.lddctx = H; at.delta = e->at<float>(e->o_delta); at.dqkv = dqkv; at.lddqkv = 3 * H;
-    at.colpart = e->at<float>(e->o_qkvcol) + (int64_t)l * (B * ((S + 127) / 128) * 4) * 3 * H;
+    at.colpart = e->at<float>(e->o_qkvcol); at.colpart_accumulate = l != L - 1;
     TRY(plb_launch_attn_bwd(&at, s));
     if (Tp > T) HIPTRY(hipMemsetAsync(dqkv + (int64_t)T * 3 * H, 0, (size_t)(Tp - T) * 3 * H * 2, s));
     // dX = dQKV · Wqkv + dpre1
@@ -995,14 +1005,17 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   TRY(plb_launch_colsum(em.partials, 0, (size_t)e->emb_blocks, 2 * E, 2 * E, e->grd(PLB_EMB_LN_W), 2 * E, 0, scratch2, 1, s2));
   // token_type row 0 receives every token's gradient = the column sums of dpos
   TRY(plb_launch_colsum(e->grd(PLB_POS_EMB), 0, (size_t)e->P, E, E, e->grd(PLB_TYPE_EMB), E, 0, scratch2, 1, s2));
-  // Q/K/V biases: the attention-backward kernels left column sums of every 32-row patch they stored ([L][B*QT*4][3H])
-  TRY(plb_launch_colsum(e->at<float>(e->o_qkvcol), 0, (size_t)L * (B * ((S + 127) / 128) * 4), 3 * H, 3 * H, e->grd(PLB_Q_B),
-                        3 * H, 0, scratch2, 32, s2));
+  // Q/K/V biases: the attention-backward kernels summed, over the L applications, the column sums of every 32-row patch
+  // they stored ([B*QT*4][3H])
+  TRY(plb_launch_colsum(e->at<float>(e->o_qkvcol), 0, (size_t)(B * ((S + 127) / 128) * 4), 3 * H, 3 * H, e->grd(PLB_Q_B),
+                        3 * H, 0, scratch2, 16, s2));
   if (du_rows > 0)
     TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 16, s2));
   else
     TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 64, s2));
-  // LayerNorm-backward partials [L*blocks][3H]: dgamma | dbeta | column sums of dx. The third block is the bias
+  // LayerNorm-backward partials [L*blocks][3H]: dgamma | dbeta | column sums of dx. (Summing the L applications into
+  // one image inside the kernel — PlbLayerNorm.accumulate — was measured: the read-modify-write costs the main stream
+  // 2.5 us per launch to save side-stream traffic that is hidden behind the weight-gradient GEMMs anyway.) The third block is the bias
   // gradient of the Linear that produced the LayerNorm's input (dense.bias = colsum(dpre1), ffn_output.bias =
   // colsum(dpre2)): no pass over the stacked gradients.
   const size_t prow = (size_t)L * e->ln_blocks;

@@ -76,15 +76,10 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(PlbGemmTN p) {
   // group — speed only, never correctness): XCD x takes splits [x*s, (x+1)*s), all their tiles.
   const int nbk = p.K >> 8;
   const int tiles = (p.Ncols >> 8) * nbk;
-  int split, tile;
-  if ((p.splits & 7) == 0) {
-    const int spx = p.splits >> 3, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    split = xcd * spx + slot / tiles;
-    tile = slot % tiles;
-  } else {
-    split = blockIdx.x / tiles;
-    tile = blockIdx.x % tiles;
-  }
+  // xcd_remap hands XCD x the x-th contiguous run of the logical order (split-major): whole splits when their count
+  // is a multiple of 8, otherwise a split may straddle two XCDs (its rows are then fetched by both L2s).
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = logical / tiles, tile = logical % tiles;
   const int bn = tile / nbk, bk = tile % nbk;
   const int t_begin = split * p.rows_per_split;
   int t_end = t_begin + p.rows_per_split;

@@ -99,6 +99,8 @@ typedef struct {
   const bf16_t* dy; int lddy;
   bf16_t* dx; int lddx;
   float* partials; int nblocks;
+  int accumulate;               // backward: add to partials instead of overwriting (the 12 applications of the shared
+                                // layer sum into ONE [nblocks][3H] image: launches are ordered, so is the sum)
   // fp8 copy of the output for the fp8 GEMM that consumes it (H = 768 / 1024 kernels only): forward y8 = e4m3(y * s),
   // backward dx8 = e5m2(dx * s); q_amax collects max |value| (the next step's scale); all NULL = off
   uint8_t* out8; int ld8; const float* q_scale; float* q_amax;
@@ -139,6 +141,7 @@ typedef struct {
   float* delta;                 // [B,NH,S]
   bf16_t* dqkv; int lddqkv;     // [T,3H]
   float* colpart;               // backward, optional: [B * ceil(S/128) * 4][3H] column sums of dqkv per (sample, 128-row tile, wave)
+  int colpart_accumulate;       // add to colpart instead of overwriting (sum over the applications of the shared layer)
 } PlbAttn;
 int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream);
 int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream);  // dq (+delta) then dk,dv

@@ -316,8 +316,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(PlbLayerNorm p) {
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * H; i += 256) {  // partials[block][dgamma | dbeta | colsum(dx)]
     const int which = i / H, col = i % H;
-    p.partials[(size_t)blockIdx.x * 3 * H + i] =
-        red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+    float* dst = &p.partials[(size_t)blockIdx.x * 3 * H + i];
+    const float v = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+    *dst = p.accumulate ? *dst + v : v;
   }
 }
 
@@ -569,8 +570,9 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_kernel(PlbLayerNorm p) {
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * H; i += 256) {
     const int which = i / H, col = i % H;
-    p.partials[(size_t)blockIdx.x * 3 * H + i] =
-        red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+    float* dst = &p.partials[(size_t)blockIdx.x * 3 * H + i];
+    const float v = red[0][which][col] + red[1][which][col] + red[2][which][col] + red[3][which][col];
+    *dst = p.accumulate ? *dst + v : v;
   }
 }
 
