@@ -631,12 +631,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* X, size_t R, in
   }
 }
 
-__global__ void reduce_slabs_kernel(const float* slab, int splits, size_t n, float* out, int accumulate) {
+// out[i] (+)= sum over the splits, in split order (fixed: deterministic). Four slabs are loaded before the first add:
+// the loop is a chain of dependent HBM reads otherwise (1.9 TB/s measured with one load in flight per thread).
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slab, int splits, size_t n, float* out, int accumulate) {
   const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   if (i + 4 <= n) {
     float4 s = accumulate ? *(const float4*)(out + i) : make_float4(0, 0, 0, 0);
-    for (int k = 0; k < splits; ++k) {
+    int k = 0;
+    for (; k + 4 <= splits; k += 4) {
+      const float4 v0 = *(const float4*)(slab + (size_t)k * n + i), v1 = *(const float4*)(slab + (size_t)(k + 1) * n + i);
+      const float4 v2 = *(const float4*)(slab + (size_t)(k + 2) * n + i), v3 = *(const float4*)(slab + (size_t)(k + 3) * n + i);
+      s.x = (((s.x + v0.x) + v1.x) + v2.x) + v3.x; s.y = (((s.y + v0.y) + v1.y) + v2.y) + v3.y;
+      s.z = (((s.z + v0.z) + v1.z) + v2.z) + v3.z; s.w = (((s.w + v0.w) + v1.w) + v2.w) + v3.w;
+    }
+    for (; k < splits; ++k) {
       float4 v = *(const float4*)(slab + (size_t)k * n + i);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
