@@ -130,9 +130,11 @@ def cpu_baseline(budget_s):
 # profiler class -> does a rocprof kernel name belong to it (template arguments: <tile, ACT, OUTF32, loop form>)
 def _in_class(cls, name):
     import re
+    if cls == "gemm_nt_small":
+        return re.search(r"gemm_nt_kernel<\d+, false>", name) is not None
     if cls in ("gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32"):
         m = re.search(r"gemm_nt_big_kernel<\d+, (\d+), (false|true), (?:false|true)(?:, (?:false|true))*>", name) or \
-            re.search(r"gemm_nt_kernel<(\d+), (false|true)>", name)
+            (re.search(r"gemm_nt_kernel<(\d+), (true)>", name) if cls == "gemm_nt_f32" else None)
         if not m:
             return False
         act, f32 = int(m.group(1)), m.group(2) == "true"
@@ -248,7 +250,7 @@ class StagedFeeder:
 
 # HBM-bound kernel classes of the step and the roofline they are priced against
 MEMORY_BOUND = ("embed_fwd", "embed_bwd", "ln_fwd", "ln_bwd", "colsum", "reduce_slabs", "cross_entropy", "adamw",
-                "gather_scatter_rows", "cast_transpose")
+                "gather_scatter_rows", "cast_transpose", "fp8_quantize")
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 
 

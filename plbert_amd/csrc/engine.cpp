@@ -43,7 +43,7 @@ std::vector<hipEvent_t> g_pool;
 const char* const kClassNames[PLB_K_NCLASS] = {
     "gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32", "gemm_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv",
     "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "reduce_slabs", "gather_scatter_rows", "cross_entropy",
-    "adamw", "cast_transpose", "token_ce", "gemm_nt_ce"};
+    "adamw", "cast_transpose", "token_ce", "gemm_nt_ce", "gemm_nt_small", "fp8_quantize"};
 hipEvent_t prof_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
@@ -1019,10 +1019,10 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   // gradient of the Linear that produced the LayerNorm's input (dense.bias = colsum(dpre1), ffn_output.bias =
   // colsum(dpre2)): no pass over the stacked gradients.
   const size_t prow = (size_t)L * e->ln_blocks;
-  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch2, 16, s2));
-  TRY(plb_launch_copy_cols(scratch2, 16, 3 * H, 2 * H, H, e->grd(PLB_DENSE_B), s2));
-  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch2, 16, s2));
-  TRY(plb_launch_copy_cols(scratch2, 16, 3 * H, 2 * H, H, e->grd(PLB_FFNO_B), s2));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch2, 64, s2));
+  TRY(plb_launch_copy_cols(scratch2, 64, 3 * H, 2 * H, H, e->grd(PLB_DENSE_B), s2));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch2, 64, s2));
+  TRY(plb_launch_copy_cols(scratch2, 64, 3 * H, 2 * H, H, e->grd(PLB_FFNO_B), s2));
   if (s2 != s) HIPTRY(hipEventRecord(e->ev_join, s2));
   // main stream: shared-layer weight gradients, one token-major GEMM per weight over all L applications ------------
   // Overlapped exchange: a weight's range travels as soon as its GEMM (+ slab reduction) has written it. The small

@@ -264,7 +264,9 @@ extern "C" int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipS
     plb_prof_end(tokb, stream);
     return rc;
   }
-  const int tok = plb_prof_begin(cls, stream, 2.0 * mnk, algo_bytes);
+  // the 128x128 kernel (head, map-in and other small products; some run on the engine's side stream, where a launch
+  // can sit behind the main stream's grid for longer than it runs) is a class of its own: "gemm_nt" is the pipeline kernel
+  const int tok = plb_prof_begin(out_f32 ? PLB_K_GEMM_NT_F32 : PLB_K_GEMM_NT_SMALL, stream, 2.0 * mnk, algo_bytes);
   if (out_f32) {
     if (act != 0) return 1;
     hipLaunchKernelGGL((gemm_nt_kernel<0, true>), grid, block, 0, stream, *p);

@@ -1096,6 +1096,7 @@ extern "C" int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols
   if (!rows || cols <= 0 || cols % 8 || ld % 8) return 1;
   const size_t n = rows * (size_t)(cols / (is_bf16 ? 8 : 4));
   unsigned blocks = (unsigned)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+  ProfScope ps(PLB_K_FP8, stream, 0, (double)rows * cols * (is_bf16 ? 2 : 4));
   if (is_bf16) hipLaunchKernelGGL((amax_kernel<true>), dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld, amax);
   else hipLaunchKernelGGL((amax_kernel<false>), dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld, amax);
   return LAUNCH_OK();
@@ -1110,6 +1111,7 @@ extern "C" int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int 
   if (!rows || cols <= 0 || cols % 8 || ld % 8 || ldo % 8) return 1;
   const size_t n = rows * (size_t)(cols / 8);
   unsigned blocks = (unsigned)((n + 255) / 256); if (blocks > 2048) blocks = 2048;
+  ProfScope ps(PLB_K_FP8, stream, 0, (double)rows * cols * (is_bf16 ? 3 : 5));
   if (is_bf16) hipLaunchKernelGGL((quantize_kernel<true>), dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld, scale, out, ldo, bf8);
   else hipLaunchKernelGGL((quantize_kernel<false>), dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld, scale, out, ldo, bf8);
   return LAUNCH_OK();

@@ -56,10 +56,11 @@ def test_dual_adamw_trajectory_golden():
         eng.adamw_step(step, lr=1e-3)
     torch.cuda.synchronize()
     assert np.allclose(losses, g["losses"], rtol=2e-3)
-    for k in ("token_predictor.weight", "token_predictor.bias", "phoneme_predictor.weight"):
+    for k in ("token_predictor.weight", "token_predictor.bias", "phoneme_predictor.weight",
+              "encoder.encoder.albert_layer_groups.0.albert_layers.0.ffn.weight", "encoder.embeddings.word_embeddings.weight"):
         d_got = eng.view(k).cpu() - torch.from_numpy(sd[k])
         d_ref = torch.from_numpy(g["final/" + k] - sd[k])
-        assert rel_l2(d_got, d_ref) < 0.25, (k, rel_l2(d_got, d_ref))
+        assert rel_l2(d_got, d_ref) < 0.12, (k, rel_l2(d_got, d_ref))   # bf16 gradient noise through Adam (measured <= 0.1)
     # a phoneme-only step afterwards leaves the token head alone (no gradient -> no update, as torch)
     before = eng.view("token_predictor.weight").clone()
     eng.loss_fwd_bwd(masked, labels, lens, off, flat, n)

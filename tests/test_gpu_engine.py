@@ -97,13 +97,20 @@ def test_adamw_trajectory_small():
         eng.adamw_step(step, lr=1e-3)
     torch.cuda.synchronize()
     assert np.allclose(losses, g["losses"], rtol=2e-3)
-    # Adam's first steps move every weight by ~lr regardless of gradient scale: compare the update
-    # direction in aggregate (relative L2 of the parameter change)
-    for k in ("encoder.encoder.albert_layer_groups.0.albert_layers.0.ffn.weight", "phoneme_predictor.weight",
-              "encoder.embeddings.word_embeddings.weight"):
-        d_got = eng.view(k).cpu() - torch.from_numpy(sd[k])
+    # The optimizer arithmetic itself is pinned to 1e-6 against torch (tests/test_gpu_adamw_kernel.py); what is left
+    # here is the bf16 backward's gradient noise seen through Adam's first steps, which move every weight by ~lr times
+    # sign-like m / sqrt(v). EVERY tensor's parameter change is compared (relative L2; measured 0.02-0.10). The key bias
+    # is excluded: its true gradient is 0 (softmax shift invariance), so Adam turns rounding noise into +-lr steps in
+    # the reference as well as here.
+    for k in g.files:
+        if not k.startswith("final/") or k.endswith("attention.key.bias"):
+            continue
+        k = k[len("final/"):]
         d_ref = torch.from_numpy(g["final/" + k] - sd[k])
-        assert rel_l2(d_got, d_ref) < 0.25, (k, rel_l2(d_got, d_ref))
+        if float(d_ref.norm()) == 0.0:
+            continue
+        d_got = eng.view(k).cpu() - torch.from_numpy(sd[k])
+        assert rel_l2(d_got, d_ref) < 0.12, (k, rel_l2(d_got, d_ref))
     assert torch.equal(eng.view("encoder.pooler.weight").cpu(), torch.from_numpy(sd["encoder.pooler.weight"]))
 
 
