@@ -31,6 +31,12 @@ static int fail(const char* fmt, ...) {
 }
 extern "C" const char* plb_last_error(void) { return g_err; }
 
+// Events that only order one HIP stream of this engine behind another: no timing, and a DEVICE-scope release when
+// recorded (the default is a system-scope release, i.e. an L2 write-back for the host's benefit: nobody on the host
+// reads what these events publish).
+static const unsigned kStreamOrderEvent = hipEventDisableTiming | hipEventReleaseToDevice;
+
+
 // ---- per-launch HIP-event profiler ----------------------------------------------------------------------
 // When enabled every launcher brackets its kernel with two events on the launch stream; reading
 // synchronises on them and sums elapsed time, launches and algorithmic flops/bytes per kernel class.
@@ -429,8 +435,8 @@ extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_av
   e->ws = (char*)workspace;
   if (!e->side && grads) {  // created once, outside any launch sequence (a step may be graph-captured)
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side = nullptr;
-    if (e->side && (hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) != hipSuccess ||
-                    hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) != hipSuccess)) {
+    if (e->side && (hipEventCreateWithFlags(&e->ev_fork, kStreamOrderEvent) != hipSuccess ||
+                    hipEventCreateWithFlags(&e->ev_join, kStreamOrderEvent) != hipSuccess)) {
       (void)hipStreamDestroy(e->side);
       e->side = nullptr;
     }
@@ -1123,8 +1129,8 @@ extern "C" int plb_comm_init(PlbEngine* e, const uint8_t id[PLB_COMM_ID_BYTES], 
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
   HIPTRY(hipStreamCreateWithPriority(&e->comm_stream, hipStreamNonBlocking, hi));
-  HIPTRY(hipEventCreateWithFlags(&e->ev_piece, hipEventDisableTiming));
-  HIPTRY(hipEventCreateWithFlags(&e->ev_comm_done, hipEventDisableTiming));
+  HIPTRY(hipEventCreateWithFlags(&e->ev_piece, kStreamOrderEvent));
+  HIPTRY(hipEventCreateWithFlags(&e->ev_comm_done, kStreamOrderEvent));
   RcclId u;
   memcpy(&u, id, sizeof(u));
   const int rc = g_rccl.CommInitRank(&e->comm, world, u, rank);
