@@ -310,9 +310,21 @@ def main():
         flop_per_token = FLOP_PER_TOKEN_STEP
         model_desc = "hidden 768 / 12 shared layers / FFN 2048 / 12 heads"
     B, S = args.batch, args.seq
-    trainer = PLBertTrainer(cfg, num_phonemes=len(plbert_amd.symbols), max_batch=B, max_seq=S, lr=7e-5,
-                            device=f"cuda:{dev_index}", seed=0, force_collectives=args.force_dist,
-                            num_tokens=args.num_tokens, comm=comm_mode, overlap=args.overlap != "off")
+    def make_trainer(mode, group=None):
+        return PLBertTrainer(cfg, num_phonemes=len(plbert_amd.symbols), max_batch=B, max_seq=S, lr=7e-5,
+                             device=f"cuda:{dev_index}", seed=0, force_collectives=args.force_dist,
+                             num_tokens=args.num_tokens, comm=mode, overlap=args.overlap != "off", process_group=group)
+
+    comm_note = None
+    try:
+        trainer = make_trainer(comm_mode)
+    except Exception as ex:  # the scaling run must produce a number: say what failed and exchange through torch instead
+        if comm_mode != "rccl" or not dist.is_initialized() or shared:
+            raise
+        comm_note = f"plb_comm_init failed ({ex}); gradients exchanged by torch.distributed (nccl = RCCL) instead"
+        print("bench.py: " + comm_note, file=sys.stderr, flush=True)
+        comm_mode = "torch"
+        trainer = make_trainer("torch", dist.new_group(backend="nccl"))
     eng = trainer.engine
     if args.dtype == "fp8":
         eng.set_fp8(True)
@@ -352,6 +364,8 @@ def main():
         return loss
 
     comm_info = {"mode": trainer.comm, "control_plane": "gloo" if dist.is_initialized() else None}
+    if comm_note:
+        comm_info["note"] = comm_note
     ranks_seen = 1
     if trainer.comm == "rccl":
         # every rank adds a one through the engine's communicator: the sum is the number of ranks that took part
@@ -365,9 +379,9 @@ def main():
         eng.set_grad_overlap(args.overlap != "off")
     elif trainer.comm == "torch":
         t = torch.ones(1, device=eng.device)
-        dist.all_reduce(t)
+        dist.all_reduce(t, group=trainer.reducer.group)
         ranks_seen = int(round(float(t.item())))
-        comm_info.update(backend=dist.get_backend(), shared_devices=shared)
+        comm_info.update(backend=dist.get_backend(trainer.reducer.group), shared_devices=shared)
     if trainer.comm != "none":
         # Creating a communicator leaves the process slow for some hundred milliseconds (measured at world size 1:
         # 12.4 instead of 10.8 ms/step over the 25 steps that follow it): settle untimed. A FIXED number of steps:

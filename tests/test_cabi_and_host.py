@@ -135,19 +135,25 @@ def test_validate_token_ids_and_five_tuple_staging_checks():
 
 def test_bench_maps_profiler_classes_to_rocprof_kernel_names():
     """bench.py attributes PMC traffic to the dominant profiler class by kernel name (template arguments
-    <tile, ACT, OUTF32, loop form> of the pipeline GEMM, <ACT, OUTF32> of the 128x128 one)."""
+    <tile, ACT, OUTF32, loop form, FP8, ABF8> of the pipeline GEMM, <ACT, OUTF32> of the 128x128 one, which is a class
+    of its own: some of its launches queue on the side stream)."""
     import importlib.util
 
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    big = "void (anonymous namespace)::gemm_nt_big_kernel<%d, %d, %s, true>(PlbGemmNT)"
+    big = "void (anonymous namespace)::gemm_nt_big_kernel<%d, %d, %s, true, false, false>(PlbGemmNT)"
+    assert bench._in_class("gemm_nt", "void (anonymous namespace)::gemm_nt_big_kernel<3, 0, false, true>(PlbGemmNT)")  # round-1 names
+    assert bench._in_class("gemm_nt", "void (anonymous namespace)::gemm_nt_big_kernel<3, 0, false, true, true, true>(PlbGemmNT)")
     assert bench._in_class("gemm_nt", big % (3, 0, "false"))
     assert not bench._in_class("gemm_nt", big % (2, 1, "false"))
     assert bench._in_class("gemm_nt_gelu", big % (2, 1, "false"))
     assert bench._in_class("gemm_nt_gelubwd", big % (2, 2, "false"))
     assert bench._in_class("gemm_nt_f32", big % (2, 0, "true")) and not bench._in_class("gemm_nt", big % (2, 0, "true"))
-    assert bench._in_class("gemm_nt", "void (anonymous namespace)::gemm_nt_kernel<0, false>(PlbGemmNT)")
+    small = "void (anonymous namespace)::gemm_nt_kernel<0, false>(PlbGemmNT)"
+    assert bench._in_class("gemm_nt_small", small) and not bench._in_class("gemm_nt", small)
+    assert bench._in_class("gemm_nt_f32", "void (anonymous namespace)::gemm_nt_kernel<0, true>(PlbGemmNT)")
+    assert not bench._in_class("gemm_nt_small", big % (3, 0, "false"))
     assert bench._in_class("gemm_tn", "(anonymous namespace)::gemm_tn_big_kernel(PlbGemmTN)")
     assert not bench._in_class("gemm_nt", "(anonymous namespace)::gemm_tn_big_kernel(PlbGemmTN)")
     assert bench._in_class("attn_bwd_dkv", "(anonymous namespace)::attn_bwd_dkv_kernel(PlbAttn)")
