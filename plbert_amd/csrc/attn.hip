@@ -41,6 +41,14 @@ DEVI bf16x8 row_frag(const bf16_t* tile, int rb, int ks, int lane) {
   const int row = rb * 32 + (lane & 31);
   return *(const bf16x8*)&tile[row_off(row, ks * 2 + (lane >> 5))];
 }
+// The four lane-constant element offsets of row_frag(tile, 0, ks, lane), ks = 0..3 (row block rb adds rb*2048): the XOR
+// swizzle keeps them from being one base + immediates, so the kernels compute them once instead of per tile.
+DEVI void row_frag_offsets(int lane, int (&off)[4]) {
+  const int row = lane & 31;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) off[ks] = row_off(row, ks * 2 + (lane >> 5));
+}
+#define ROW_FRAG(tile, rb, ks, off) (*(const bf16x8*)&(tile)[(off)[ks] + (rb) * 2048])
 // registers 8s..8s+7 of a 32x32 accumulator -> bf16x8 operand fragment (k-step s)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 DEVI bf16x8 acc_frag(const f32x16& x, int s) {
@@ -98,7 +106,10 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
 }
 
 // ---------------------------------------------------------------------------------------- forward
-__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(PlbAttn p) {
+#ifndef FWD_WAVES
+#define FWD_WAVES 3   // waves per SIMD the register allocation is held to
+#endif
+__global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][64 * 64];  // [stage][K row | V tr] 32 KiB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // 1-D grid, XCD-aware: the q-tiles of one (batch, head) read the same K/V, so they get consecutive
@@ -152,62 +163,65 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(PlbAttn p) {
   float m_run = -INFINITY, l_run = 0.f;
   const float sl2 = p.scale * LOG2E;
 
+  int kqo[4];
+  row_frag_offsets(lane, kqo);
   KV_LOAD(0);
   KV_STORE(0);
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    KV_LOAD(kt + 1 < nkt ? kt + 1 : kt);
-    const bf16_t* sK = smem[cur][0];
-    const bf16_t* sV = smem[cur][1];
-    f32x16 s0 = zero16(), s1 = zero16();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, 0, ks, lane), qf[ks], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, 1, ks, lane), qf[ks], s1, 0, 0, 0);
-    }
-    // Softmax in the exp2 domain. The loop is VALU-bound at head_dim 64 (one v_exp per score against
-    // 256 MFMA flops), so: masking only in a tile that crosses the length, the scale folded into one
-    // FMA per score (max taken on raw scores: the scale is positive), and the accumulator rescaled only
-    // when some query's running max actually moved (exact: alpha == 1 otherwise).
-    float mx = -INFINITY;
-    if (kt * 64 + 64 > len) {
-      const int kbase_i = kt * 64 + 4 * h;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kr0 = kbase_i + (r & 3) + 8 * (r >> 2);
-        s0[r] = (kr0 < len) ? s0[r] : -INFINITY;
-        s1[r] = (kr0 + 32 < len) ? s1[r] : -INFINITY;
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(fmaxf(s0[r], s0[r + 1]), fmaxf(s1[r], s1[r + 1])));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * sl2);   // finite: the first tile always holds key 0 < len
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      m_run = m_new;
-    }
-    float ls = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -m_new));
-      s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -m_new));
-      ls += s0[r] + s1[r];
-    }
-    l_run += ls;
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-      const bf16x8 pb = acc_frag((s4 >> 1) ? s1 : s0, s4 & 1);
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, s4 >> 1, s4 & 1, 0, lane), pb, o0, 0, 0, 0);
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, s4 >> 1, s4 & 1, 1, lane), pb, o1, 0, 0, 0);
-    }
-    KV_STORE(cur ^ 1);
-    __syncthreads();
+  // One tile of 64 keys out of LDS stage CUR (a literal: every LDS address below is a lane constant + an immediate; with
+  // a run-time stage hipcc re-derived ~45 address VALU per tile in a VALU-bound loop). The loop runs two tiles per trip.
+#define FWD_TILE(CUR, kt)                                                                                         \
+  do {                                                                                                            \
+    KV_LOAD((kt) + 1 < nkt ? (kt) + 1 : (kt));                                                                    \
+    const bf16_t* sK = smem[CUR][0];                                                                              \
+    const bf16_t* sV = smem[CUR][1];                                                                              \
+    f32x16 s0 = zero16(), s1 = zero16();                                                                          \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                            \
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ROW_FRAG(sK, 0, ks, kqo), qf[ks], s0, 0, 0, 0);                \
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ROW_FRAG(sK, 1, ks, kqo), qf[ks], s1, 0, 0, 0);                \
+    }                                                                                                             \
+    /* Softmax in the exp2 domain. The loop is VALU-bound at head_dim 64 (one v_exp per score against 256 MFMA */ \
+    /* flops), so: masking only in a tile that crosses the length, the scale folded into one FMA per score (max */\
+    /* taken on raw scores: the scale is positive), the row maximum as a chain of three-input maxima, and the */   \
+    /* accumulator rescaled only when some query's running max actually moved (exact: alpha == 1 otherwise). */   \
+    if ((kt) * 64 + 64 > len) {                                                                                   \
+      const int kbase_i = (kt) * 64 + 4 * h;                                                                      \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                            \
+        const int kr0 = kbase_i + (r & 3) + 8 * (r >> 2);                                                         \
+        s0[r] = (kr0 < len) ? s0[r] : -INFINITY;                                                                  \
+        s1[r] = (kr0 + 32 < len) ? s1[r] : -INFINITY;                                                             \
+      }                                                                                                           \
+    }                                                                                                             \
+    float mx = fmaxf(s0[0], s1[0]);                                                                               \
+    _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s0[r]), s1[r]);       \
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                       \
+    const float m_new = fmaxf(m_run, mx * sl2); /* finite: the first tile always holds key 0 < len */             \
+    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {                                                       \
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                  \
+      l_run *= alpha;                                                                                             \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }                          \
+      m_run = m_new;                                                                                              \
+    }                                                                                                             \
+    float ls = 0.f;                                                                                               \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
+      s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -m_new));                                         \
+      s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -m_new));                                         \
+      ls += s0[r] + s1[r];                                                                                        \
+    }                                                                                                             \
+    l_run += ls;                                                                                                  \
+    _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                            \
+      const bf16x8 pb = acc_frag((s4 >> 1) ? s1 : s0, s4 & 1);                                                    \
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, s4 >> 1, s4 & 1, 0, lane), pb, o0, 0, 0, 0);       \
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, s4 >> 1, s4 & 1, 1, lane), pb, o1, 0, 0, 0);       \
+    }                                                                                                             \
+    KV_STORE((CUR) ^ 1);                                                                                          \
+    __syncthreads();                                                                                              \
+  } while (0)
+  for (int kt = 0; kt < nkt; kt += 2) {
+    FWD_TILE(0, kt);
+    if (kt + 1 < nkt) FWD_TILE(1, kt + 1);
   }
+#undef FWD_TILE
 #undef KV_LOAD
 #undef KV_STORE
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
