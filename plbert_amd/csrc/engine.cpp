@@ -192,6 +192,7 @@ struct PlbEngine {
   bool overlap = true;          // issue the all-reduce piecewise inside plb_loss_fwd_bwd
   bool comm_pending = false;    // pieces were issued: plb_allreduce_grads / plb_adamw_step must join ev_comm_done
   bool grads_reduced = false;   // the gradients of the last loss call have been all-reduced
+  int64_t piece_floats = 0;     // floats submitted as pieces by the current loss call (must add up to the gradient range)
   // bound buffers
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
   char* ws = nullptr;
@@ -747,12 +748,18 @@ static int reduce_piece(PlbEngine* e, int64_t a, int64_t b, hipStream_t after) {
   const int rc = g_rccl.AllReduce(e->grads + a, e->grads + a, (size_t)(b - a), kNcclFloat32, kNcclSum, e->comm, e->comm_stream);
   if (rc != kNcclSuccess) return fail("ncclAllReduce: %s", g_rccl.GetErrorString(rc));
   e->comm_pending = true;
+  e->piece_floats += b - a;
   return 0;
 }
 static bool overlapping(const PlbEngine* e) { return e->comm && e->overlap; }
 // Close the pieces issued so far: later joins wait on ev_comm_done.
 static int pieces_done(PlbEngine* e) {
   if (!e->comm_pending) return 0;
+  // the pieces are disjoint by construction; together they must be exactly the range AdamW is about to consume (a
+  // one-rank communicator would not show a forgotten tensor: its all-reduce is the identity)
+  const int64_t want = e->ptrain + (e->tok_grads_live ? e->ptotal - e->poff[PLB_TOK_W] : 0);
+  if (e->piece_floats != want)
+    return fail("gradient exchange covered %lld of %lld floats", (long long)e->piece_floats, (long long)want);
   HIPTRY(hipEventRecord(e->ev_comm_done, e->comm_stream));
   e->grads_reduced = true;
   return 0;
@@ -779,13 +786,22 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     e->tok_grads_live = token_targets != nullptr;
     e->comm_pending = false;
     e->grads_reduced = false;
+    e->piece_floats = 0;
   }
   if (n_masked == 0 && !token_targets) {  // train.py:129 — zero loss, nothing to back-propagate
     HIPTRY(hipMemsetAsync(loss, 0, sizeof(float), s));
     if (backward) {
       HIPTRY(hipMemsetAsync(e->grads, 0, (size_t)e->ptrain * 4, s));
-      if (overlapping(e)) {  // the other ranks still contribute theirs
-        if (reduce_piece(e, 0, e->ptrain, s)) return 1;
+      if (overlapping(e)) {
+        // The other ranks still contribute theirs — and they issue the pieces of a regular step: a collective
+        // sequence must be the same on every rank, so this rank issues the very same ranges in the very same order
+        // (its zeros), not one all-reduce of the whole buffer.
+        const int64_t* o = e->poff;
+        const int64_t ranges[8][2] = {{o[PLB_HEAD_W], e->ptrain}, {o[PLB_Q_W], o[PLB_Q_B]}, {o[PLB_FFN_W], o[PLB_FFN_B]},
+                                      {o[PLB_FFNO_W], o[PLB_FFNO_B]}, {0, o[PLB_Q_W]}, {o[PLB_Q_B], o[PLB_FFN_W]},
+                                      {o[PLB_FFN_B], o[PLB_FFNO_W]}, {o[PLB_FFNO_B], o[PLB_HEAD_W]}};
+        for (auto& r : ranges)
+          if (reduce_piece(e, r[0], r[1], s)) return 1;
         if (pieces_done(e)) return 1;
       }
     }
