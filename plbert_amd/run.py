@@ -1,0 +1,232 @@
+"""Run management of the hot path's caller: what ``train.train(args)`` does around the step in the
+reference — run directory + resume-by-directory (train.py:174-210), latest-checkpoint discovery (train.py:46-79),
+validation before the first step and at every ``save_interval`` (train.py:288-336,344,369-373), ``step_N.pth`` files
+(train.py:412-425) — around the MI355X-native step (``PLBertTrainer``: plb_loss_fwd_bwd -> RCCL exchange -> plb_adamw_step)
+and input pipeline (``DeviceFeeder``).
+
+Differences from the reference, on purpose: metrics go to ``<run dir>/metrics.jsonl`` and stdout instead of wandb
+(out of scope); the dataset may be handed in as any sequence of ``{'phonemes': [...]}`` rows
+(the reference's hub download, train.py:245, needs a network); ``num_workers`` and device-side masking are options of
+``training_params`` (``num_workers``, ``device_masking``) that default to the reference's behaviour (0 / off).
+
+    python -m plbert_amd.run --config_path configs/config.yml --run_name default        # train.py:27-32
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import shutil
+from collections import deque
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import yaml
+
+from .checkpoint import find_latest_checkpoint
+from .config import albert_config_from_yaml
+from .data import build_dataloader
+from .dist import shard_batch, world_info
+from .symbols import symbols
+
+MAX_EPOCHS = 10  # train.py:145
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config_path", type=str, default="configs/config.yml")
+    ap.add_argument("--run_name", type=str, default="default")
+    return vars(ap.parse_args(argv))
+
+
+def setup_config_and_directories(args, config_path):
+    """Run folder decides: an existing folder that holds a copy of the config RESUMES with that copy; an existing folder
+    without one is cleaned of ``step_*`` files and starts fresh; otherwise the folder is created (train.py:174-210).
+    Returns (config, log_dir, resuming)."""
+    with open(config_path) as f:
+        given = yaml.safe_load(f)
+    log_dir = os.path.join(given["training_params"]["output_dir"], args["run_name"])
+    kept = os.path.join(log_dir, os.path.basename(config_path))
+    if os.path.isdir(log_dir) and os.path.exists(kept):
+        with open(kept) as f:
+            return yaml.safe_load(f), log_dir, True
+    if os.path.isdir(log_dir):
+        for name in os.listdir(log_dir):
+            if name.startswith("step_"):
+                os.remove(os.path.join(log_dir, name))
+    os.makedirs(log_dir, exist_ok=True)
+    shutil.copy(config_path, kept)
+    return given, log_dir, False
+
+
+class _Log:
+    """Rank-0 metrics sink: one JSON object per event, to stdout and ``metrics.jsonl`` (the reference logs the same
+    keys to wandb: phoneme_loss, phoneme_loss_avg, val_phoneme_loss, epoch, step — train.py:326-331,398-410)."""
+
+    def __init__(self, log_dir, main):
+        self.main = main
+        self.f = open(os.path.join(log_dir, "metrics.jsonl"), "a") if main else None
+
+    def __call__(self, **kv):
+        if self.main:
+            line = json.dumps(kv)
+            print(line, flush=True)
+            self.f.write(line + "\n")
+            self.f.flush()
+
+
+def _state_for_file(trainer, step, epoch):
+    """``{'net','step','epoch','optimizer'}`` with the optimizer entry in torch.optim.AdamW's layout (indices in
+    state-dict order), as train.py:416-421 writes it."""
+    eng = trainer.engine
+    names = list(eng.layout)
+    state = {}
+    tok0 = eng.token_range[0]
+    for i, n in enumerate(names):
+        off, size, shp = eng.layout[n]
+        steps = trainer.step_count if off + size <= eng.trainable else (eng.token_head_steps if eng.num_tokens and off >= tok0 else 0)
+        if steps > 0:
+            state[i] = {"step": torch.tensor(float(steps)), "exp_avg": eng.exp_avg[off:off + size].view(shp).cpu().clone(),
+                        "exp_avg_sq": eng.exp_avg_sq[off:off + size].view(shp).cpu().clone()}
+    group = {"lr": trainer.lr, "betas": tuple(trainer.betas), "eps": trainer.eps, "weight_decay": trainer.weight_decay,
+             "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+             "fused": None, "decoupled_weight_decay": True, "params": list(range(len(names)))}
+    return {"net": {k: v.cpu() for k, v in eng.state_dict().items()}, "step": step, "epoch": epoch,
+            "optimizer": {"state": state, "param_groups": [group]}}
+
+
+def save_checkpoint(trainer, current_step, log_dir, current_epoch, main=True):
+    path = os.path.join(log_dir, f"step_{current_step}.pth")
+    if main:
+        torch.save(_state_for_file(trainer, current_step, current_epoch), path)
+        print(f"Checkpoint saved at: {path}", flush=True)
+    return path
+
+
+def load_checkpoint(trainer, path):
+    """Weights (``module.`` prefixes stripped, non-strict: train.py:98-100) and, when present, the AdamW state."""
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    eng = trainer.engine
+    eng.load_state_dict({k.replace("module.", ""): v for k, v in ck["net"].items()}, strict=False)
+    opt = ck.get("optimizer")
+    if opt and opt.get("state"):
+        names = list(eng.layout)
+        eng.exp_avg.zero_()
+        eng.exp_avg_sq.zero_()
+        main_steps, tok_steps = set(), set()
+        for i, st in opt["state"].items():
+            off, size, shp = eng.layout[names[int(i)]]
+            is_tok = bool(eng.num_tokens) and off >= eng.token_range[0]
+            if off + size > eng.trainable and not is_tok:
+                continue
+            eng.exp_avg[off:off + size].view(shp).copy_(st["exp_avg"])
+            eng.exp_avg_sq[off:off + size].view(shp).copy_(st["exp_avg_sq"])
+            (tok_steps if is_tok else main_steps).add(int(float(st["step"])))
+        trainer.step_count = max(main_steps) if main_steps else 0
+        eng.token_head_steps = max(tok_steps) if tok_steps else 0
+    print(f"Checkpoint {path} loaded.", flush=True)
+    return int(ck.get("step", 0))
+
+
+def initialize_model(config, log_dir, resuming, device=None, max_batch=None):
+    """train.py:261-286: model + AdamW(lr), optional ``pretrained_model``, then the run's latest checkpoint when
+    resuming. Returns (trainer, current_step)."""
+    from .train import PLBertTrainer
+    cfg = albert_config_from_yaml(config, len(symbols))
+    tp = config["training_params"]
+    _, world = world_info()
+    per_rank = max(1, int(tp["batch_size"]) // world)           # split_batches=True: batch_size is global (train.py:220)
+    trainer = PLBertTrainer(cfg, num_phonemes=len(symbols), max_batch=max_batch or per_rank,
+                            max_seq=int(config["dataset_params"]["max_seq_length"]), lr=float(tp["learning_rate"]),
+                            device=device)
+    if config["model_params"].get("pretrained_model"):
+        print(f"Loading pretrained model from: {config['model_params']['pretrained_model']}")
+        load_checkpoint(trainer, config["model_params"]["pretrained_model"])
+    found, last = find_latest_checkpoint(log_dir)
+    current_step = 0
+    if found and resuming:
+        current_step = load_checkpoint(trainer, os.path.join(log_dir, f"step_{last}.pth")) or last
+    return trainer, current_step
+
+
+def _batches(loader, trainer, device_masking, word_separator):
+    """Collated batches of the loader as device-resident StagedBatch objects: this rank's contiguous slice of every
+    global batch (accelerate's split_batches=True), copies overlapped with compute (DeviceFeeder) on one GPU."""
+    rank, world = world_info()
+    if world == 1:
+        from .pipeline import DeviceFeeder
+        yield from DeviceFeeder(loader, device=trainer.engine.device, vocab_size=trainer.engine.cfg.vocab_size,
+                                word_separator=word_separator)
+        return
+    for batch in loader:
+        lab, msk, lens, idx = shard_batch((np.asarray(batch[0]), np.asarray(batch[1]), batch[2], batch[3]), rank, world)
+        yield trainer.stage_batch(lab, msk, lens, idx)
+
+
+def validate(trainer, val_loader, device_masking=False, word_separator=None):
+    """Mean of the per-batch losses, forward only (train.py:288-304; masks are re-drawn each pass, as there)."""
+    total, n = 0.0, 0
+    for b in _batches(val_loader, trainer, device_masking, word_separator):
+        total += float(trainer.engine.loss_fwd(b.masked, b.labels, b.lengths, b.offsets, b.flat, b.n_masked).item())
+        n += 1
+    return total / max(n, 1)
+
+
+def train_loop(trainer, train_loader, val_loader, current_step, num_steps, save_interval, log_interval, log, log_dir,
+               device_masking=False, word_separator=None, max_epochs=MAX_EPOCHS):
+    """train.py:338-379: validation first, then epochs until ``num_steps``; checkpoint + validation every
+    ``save_interval`` steps; every rank logs its LOCAL loss (the reference's rank 0 does)."""
+    main = world_info()[0] == 0
+    window = deque(maxlen=log_interval)
+    epoch = 0
+    log(val_phoneme_loss=validate(trainer, val_loader, device_masking, word_separator), step=current_step, epoch=epoch)
+    while epoch < max_epochs:
+        epoch += 1
+        for batch in _batches(train_loader, trainer, device_masking, word_separator):
+            loss = float(trainer.step(batch).item())            # the reference syncs here too (loss.item(), train.py:395)
+            current_step += 1
+            window.append(loss)
+            rec = {"phoneme_loss": loss, "epoch": epoch, "step": current_step}
+            if len(window) == log_interval:
+                rec["phoneme_loss_avg"] = float(np.mean(window))
+            log(**rec)
+            if current_step % save_interval == 0:
+                save_checkpoint(trainer, current_step, log_dir, epoch, main)
+                log(val_phoneme_loss=validate(trainer, val_loader, device_masking, word_separator), step=current_step,
+                    epoch=epoch)
+            if current_step >= num_steps:
+                return current_step, epoch
+    return current_step, epoch
+
+
+def train(args=None, dataset=None, device=None):
+    """Drop-in for ``train.train(args)`` (train.py:133-172): ``args = {'config_path', 'run_name'}``. ``dataset``: rows of
+    ``{'phonemes': [...]}``; None loads ``training_params.training_dataset`` with HF ``datasets`` as the reference does."""
+    args = args or parse_args()
+    config, log_dir, resuming = setup_config_and_directories(args, args["config_path"])
+    tp, dp = config["training_params"], dict(config["dataset_params"])
+    main = world_info()[0] == 0
+    print(f"Resuming training from '{log_dir}' with existing config." if resuming else f"Starting new training run in '{log_dir}'.")
+    if dataset is None:
+        from datasets import load_dataset
+        dataset = load_dataset(tp["training_dataset"], split=tp["split"])
+    device_masking = bool(tp.get("device_masking", False))
+    _, world = world_info()
+    train_loader, val_loader = build_dataloader(dataset, batch_size=int(tp["batch_size"]), device="cuda", dataset_config=dp,
+                                                use_token_ids=False, num_workers=int(tp.get("num_workers", 0)),
+                                                decisions=device_masking and world == 1)
+    trainer, current_step = initialize_model(config, log_dir, resuming, device=device)
+    log = _Log(log_dir, main)
+    print("Start training...")
+    current_step, epoch = train_loop(trainer, train_loader, val_loader, current_step, int(tp["num_steps"]),
+                                     int(tp["save_interval"]), int(tp["log_interval"]), log, log_dir,
+                                     device_masking and world == 1, dp.get("word_separator"))
+    print(f"Training completed at step {current_step}, epoch {epoch}")
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+    return trainer, current_step, epoch
+
+
+if __name__ == "__main__":
+    train()

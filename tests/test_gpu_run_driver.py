@@ -1,0 +1,73 @@
+"""Run management around the step (-m gpu; SURVEY.md §8(f) N1: train.py:133-210, 261-379, 412-425): a run directory is
+created with a copy of the config, validation runs first, ``step_N.pth`` files in the reference's format appear every
+``save_interval``, and calling ``train`` again on the same run name RESUMES from the latest of them."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+from conftest import load_golden
+import plbert_amd
+from plbert_amd import data as pdata
+from plbert_amd import run as prun
+
+pytestmark = pytest.mark.gpu
+
+
+def _config(tmp_path, num_steps, **training):
+    cfg = {"training_params": dict(output_dir=str(tmp_path / "runs"), batch_size=4, mixed_precision="fp16", learning_rate=1e-3,
+                                   num_steps=num_steps, save_interval=3, log_interval=2, training_dataset="unused",
+                                   split="train", **training),
+           "dataset_params": dict(max_seq_length=64, word_pred_prob=0.15, phoneme_mask_prob=0.8, replace_prob=0.1,
+                                  word_separator=87),
+           "model_params": dict(hidden_size=128, num_attention_heads=2, intermediate_size=256, max_position_embeddings=512,
+                                num_hidden_layers=2, embedding_size=64, pretrained_model="", dropout=0.1)}
+    path = tmp_path / "config.yml"
+    path.write_text(yaml.safe_dump(cfg))
+    return str(path)
+
+
+def _docs():
+    g = load_golden("masking")
+    return [{"phonemes": d.split("\x1f")} for d in g["docs"] if len(d) > 0] * 12
+
+
+@pytest.mark.parametrize("device_masking", [False, True])
+def test_run_directory_checkpoints_and_resume(tmp_path, device_masking):
+    path = _config(tmp_path, 6, device_masking=device_masking)
+    args = {"config_path": path, "run_name": "r"}
+    torch.manual_seed(0)
+    pdata.seed_reference_streams(1)
+    trainer, step, epoch = prun.train(args, dataset=_docs())
+    run_dir = tmp_path / "runs" / "r"
+    assert step == 6 and (run_dir / "config.yml").exists()
+    assert sorted(f for f in os.listdir(run_dir) if f.startswith("step_")) == ["step_3.pth", "step_6.pth"]
+    ck = torch.load(run_dir / "step_6.pth", map_location="cpu", weights_only=False)
+    assert set(ck) == {"net", "step", "epoch", "optimizer"} and ck["step"] == 6
+    assert "encoder.embeddings.word_embeddings.weight" in ck["net"] and "phoneme_predictor.weight" in ck["net"]
+    # torch's own AdamW accepts the optimizer entry (parameter order = state-dict order)
+    ps = [torch.nn.Parameter(v.clone().float()) for v in ck["net"].values()]
+    torch.optim.AdamW(ps, lr=1e-3).load_state_dict(ck["optimizer"])
+    recs = [json.loads(l) for l in (run_dir / "metrics.jsonl").read_text().splitlines()]
+    assert "val_phoneme_loss" in recs[0] and recs[0]["step"] == 0                      # validation before the first step
+    assert sum("val_phoneme_loss" in r for r in recs) == 3                             # step 0, 3, 6
+    assert [r["step"] for r in recs if "phoneme_loss" in r] == [1, 2, 3, 4, 5, 6]
+    assert all("phoneme_loss_avg" in r for r in recs if "phoneme_loss" in r and r["step"] >= 2)
+    w6 = trainer.engine.state_dict()["phoneme_predictor.weight"].cpu()
+    assert torch.equal(w6, ck["net"]["phoneme_predictor.weight"])
+    # same run name, larger budget: resumes at step 6 with the saved weights and optimizer state
+    cfg = yaml.safe_load(open(run_dir / "config.yml"))
+    cfg["training_params"]["num_steps"] = 8
+    (run_dir / "config.yml").write_text(yaml.safe_dump(cfg))
+    trainer2, step2, _ = prun.train(args, dataset=_docs())
+    assert step2 == 8 and trainer2.step_count == 8
+    recs2 = [json.loads(l) for l in (run_dir / "metrics.jsonl").read_text().splitlines()][len(recs):]
+    assert recs2[0]["step"] == 6 and "val_phoneme_loss" in recs2[0]                    # validation at the resumed step
+    assert [r["step"] for r in recs2 if "phoneme_loss" in r] == [7, 8]
+    # a folder without a config copy is cleaned and starts fresh
+    os.remove(run_dir / "config.yml")
+    _, _, resuming = prun.setup_config_and_directories(args, path)
+    assert not resuming and not [f for f in os.listdir(run_dir) if f.startswith("step_")]
