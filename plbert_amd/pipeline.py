@@ -64,13 +64,23 @@ class DeviceFeeder:
         self._prev = None
 
     # ---- producer thread: DataLoader -> packed host arrays -------------------------------------------------
-    def _produce(self, q):
+    def _put(self, q, item, stop):
+        while not stop.is_set():  # a consumer that left early (break, exception) must not strand this thread
+            try:
+                q.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _produce(self, q, stop):
         try:
             for item in self.loader:
-                q.put(self._host_pack(item))
-            q.put(None)
+                if not self._put(q, self._host_pack(item), stop):
+                    return
+            self._put(q, None, stop)
         except BaseException as ex:  # surfaced in the consumer
-            q.put(ex)
+            self._put(q, ex, stop)
 
     def _host_pack(self, item):
         if isinstance(item, dict):  # collate_decisions
@@ -123,8 +133,19 @@ class DeviceFeeder:
 
     def __iter__(self):
         q = queue.Queue(maxsize=self.prefetch)
-        th = threading.Thread(target=self._produce, args=(q,), daemon=True)
+        stop = threading.Event()
+        th = threading.Thread(target=self._produce, args=(q, stop), daemon=True)
         th.start()
+        try:
+            yield from self._consume(q)
+        finally:
+            stop.set()
+            if self._prev is not None:
+                self.release(self._prev)
+                self._prev = None
+            th.join(timeout=5)
+
+    def _consume(self, q):
         for k in range(self.depth):
             self._free[k].record(torch.cuda.current_stream(self.device))
         pending = []                                # uploaded, not yet yielded: (slot, kind, meta, info)
@@ -152,10 +173,6 @@ class DeviceFeeder:
                 batch._slot = k
                 self._prev = batch
                 yield batch
-        if self._prev is not None:
-            self.release(self._prev)
-            self._prev = None
-        th.join(timeout=5)
 
     def _stage(self, kind, meta, info, dev):
         B, S, lengths = info["B"], info["S"], info["lengths"]
