@@ -21,6 +21,9 @@ def __getattr__(name):
     if name in ("save_checkpoint", "load_checkpoint", "find_latest_checkpoint"):
         from . import checkpoint
         return getattr(checkpoint, name)
+    if name in ("export_pretrained", "encoder_state_dict", "load_pl_bert_model"):
+        from . import export
+        return getattr(export, name)
     if name == "DeviceFeeder":
         from .pipeline import DeviceFeeder
         return DeviceFeeder
@@ -32,7 +35,8 @@ def __getattr__(name):
 
 __all__ = [
     "AlbertModel", "PhonemeOnlyModel", "MultiTaskModel", "PLBertTrainer", "process_batch", "AdamW", "HipEngine",
-    "save_checkpoint", "load_checkpoint", "find_latest_checkpoint", "device_mask_batch", "device_apply_mask",
+    "save_checkpoint", "load_checkpoint", "find_latest_checkpoint", "export_pretrained", "encoder_state_dict",
+    "load_pl_bert_model", "device_mask_batch", "device_apply_mask",
     "AlbertConfig", "albert_config_from_yaml", "load_config",
     "CharacterIndexer", "symbols", "PAD_ID", "MASK_ID", "SEPARATOR_ID", "UNKNOWN_ID",
     "param_shapes", "deterministic_state_dict", "reference_init_state_dict",

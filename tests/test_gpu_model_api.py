@@ -166,3 +166,29 @@ def test_dual_head_loop_body_on_multitask_model():
         bad = torch.from_numpy(g["token_ids"]).clone()
         bad[0, 0] = int(g["num_tokens"])                               # out-of-range class id
         plbert_amd.process_batch(m, (bad,) + batch[1:], None, None)
+
+
+@pytest.mark.parametrize("multitask", [False, True])
+def test_export_and_load_pl_bert_model_round_trip(multitask, tmp_path):
+    """convert_to_hf.py:16-102 on the native path: model → directory → model, logits bit-identical; the
+    directory's encoder is what the reference model computed (fixture) within the bf16 bound."""
+    from plbert_amd import export
+    g = load_golden("small_h128_multitask" if multitask else "small_h128")
+    m, pcfg, sd = _make(g, multitask=multitask)
+    kw = {str(k): int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
+    kw.pop("vocab_size")
+    config = {"model_params": dict(kw, pretrained_model="", dropout=0.1)}
+    export.export_pretrained({"module." + k: v for k, v in m.state_dict().items()}, config, str(tmp_path), step=3, epoch=0)
+    B, S = g["labels"].shape
+    m2 = export.load_pl_bert_model(str(tmp_path), max_batch=B, max_seq=S)
+    assert type(m2).__name__ == ("MultiTaskModel" if multitask else "PhonemeOnlyModel") and not m2.training
+    ids = torch.from_numpy(g["masked"])
+    am = (~plbert_amd.length_to_mask(torch.Tensor(g["lengths"].tolist()))).int()
+    m.eval()
+    with torch.no_grad():
+        a, b = m(ids, attention_mask=am), m2(ids, attention_mask=am)
+    a, b = (a, b) if multitask else ((a,), (b,))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    v = (am != 0).numpy()
+    assert np.abs(b[0].cpu().numpy()[v] - g["logits"][v]).max() < 3e-2
