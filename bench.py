@@ -316,15 +316,26 @@ def main():
                              num_tokens=args.num_tokens, comm=mode, overlap=args.overlap != "off", process_group=group)
 
     comm_note = None
+    trainer, failure = None, None
     try:
         trainer = make_trainer(comm_mode)
     except Exception as ex:  # the scaling run must produce a number: say what failed and exchange through torch instead
         if comm_mode != "rccl" or not dist.is_initialized() or shared:
             raise
-        comm_note = f"plb_comm_init failed ({ex}); gradients exchanged by torch.distributed (nccl = RCCL) instead"
-        print("bench.py: " + comm_note, file=sys.stderr, flush=True)
-        comm_mode = "torch"
-        trainer = make_trainer("torch", dist.new_group(backend="nccl"))
+        failure = str(ex)
+    if comm_mode == "rccl" and dist.is_initialized() and not shared:
+        # the fallback is a collective decision: a rank whose communicator came up must not wait in it for one that failed
+        ok = torch.tensor([0.0 if failure else 1.0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if ok.item() < 0.5:
+            comm_note = (f"plb_comm_init failed ({failure or 'on another rank'}); gradients exchanged by "
+                         "torch.distributed (nccl = RCCL) instead")
+            print("bench.py: " + comm_note, file=sys.stderr, flush=True)
+            if trainer is not None:
+                trainer.engine.comm_destroy()
+                del trainer
+            comm_mode = "torch"
+            trainer = make_trainer("torch", dist.new_group(backend="nccl"))
     eng = trainer.engine
     if args.dtype == "fp8":
         eng.set_fp8(True)
