@@ -17,8 +17,40 @@
 
 namespace {
 
+// Timing-only builds (tools/build_ab.sh <name> -DATTN_DBG=mask; results are wrong by construction): 1 = no exponentials,
+// 2 = no MFMA, 4 = operand fragments are not read from LDS, 8 = no barriers, 16 = the kernels return at once (launch cost),
+// 32 = no tiles (prologue + epilogue only), 64 = no bias-gradient column sums, 128 = no output stores. They say where a tile's time goes.
+#ifndef ATTN_DBG
+#define ATTN_DBG 0
+#endif
+#if ATTN_DBG & 2
+DEVI f32x16 MFMA32(bf16x8 a, bf16x8 b, f32x16 c) { asm volatile("" ::"v"(a), "v"(b)); return c; }
+#else
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+#if ATTN_DBG & 1
+#define EXP2(x) (x)
+#else
+#define EXP2(x) __builtin_amdgcn_exp2f(x)
+#endif
+#if ATTN_DBG & 8
+#define TILE_SYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define TILE_SYNC() __syncthreads()
+#endif
+
+#if ATTN_DBG & 16
+#define DBG_EARLY_EXIT(p) if ((p).S > 0) return
+#else
+#define DBG_EARLY_EXIT(p)
+#endif
+#if ATTN_DBG & 32
+#define DBG_TILES(n) ((n) > 100000 ? 1 : 0)
+#else
+#define DBG_TILES(n) (n)
+#endif
+
 constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
 
 // [64 rows][64 cols] bf16, 128-B rows, chunk index XORed with (row>>1)&7: conflict-free ds_read_b128
 // for 32 consecutive rows at one chunk.
@@ -29,6 +61,9 @@ DEVI int tr_off(int row, int col) { return (((row >> 2) << 1) + (col >> 5)) * 12
 // A-operand fragment of X^T (X stored [row][col] in the tr layout): lane (m = cb*32 + (l&31), half h)
 // element j <- X[rb*32 + 16s + 8(j>>2) + 4h + (j&3)][m]
 DEVI bf16x8 tr_frag(const bf16_t* tile, int rb, int s, int cb, int lane) {
+#if ATTN_DBG & 4
+  bf16x8 f; asm volatile("; frag" : "=v"(f)); return f;
+#endif
   const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3, h = g >> 1;
   const int r0 = rb * 32 + 16 * s + 4 * h + q4;
   const int c = cb * 32 + 16 * (g & 1) + 4 * p4;
@@ -38,6 +73,9 @@ DEVI bf16x8 tr_frag(const bf16_t* tile, int rb, int s, int cb, int lane) {
 }
 // Row-layout fragment: lane (row = rb*32 + (l&31), k = ks*16 + 8h + j)
 DEVI bf16x8 row_frag(const bf16_t* tile, int rb, int ks, int lane) {
+#if ATTN_DBG & 4
+  bf16x8 f; asm volatile("; frag" : "=v"(f)); return f;
+#endif
   const int row = rb * 32 + (lane & 31);
   return *(const bf16x8*)&tile[row_off(row, ks * 2 + (lane >> 5))];
 }
@@ -48,7 +86,11 @@ DEVI void row_frag_offsets(int lane, int (&off)[4]) {
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) off[ks] = row_off(row, ks * 2 + (lane >> 5));
 }
+#if ATTN_DBG & 4
+#define ROW_FRAG(tile, rb, ks, off) row_frag(tile, rb, ks, 0)
+#else
 #define ROW_FRAG(tile, rb, ks, off) (*(const bf16x8*)&(tile)[(off)[ks] + (rb) * 2048])
+#endif
 // registers 8s..8s+7 of a 32x32 accumulator -> bf16x8 operand fragment (k-step s)
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 DEVI bf16x8 acc_frag(const f32x16& x, int s) {
@@ -95,14 +137,44 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
   for (int i = 0; i < 4; ++i) {
     const int id = lane + 64 * i, row = id >> 3, c = id & 7;
     uint4 v = *(const uint4*)&patch[row * PS + c * 8];
-    if (row < rows_valid) *(uint4*)(gout + (size_t)row * ldo + c * 8) = v;
+    if (row < rows_valid && (!(ATTN_DBG & 128) || v.x == 0x12345678u)) *(uint4*)(gout + (size_t)row * ldo + c * 8) = v;
   }
-  if (colsum) {
+  if (colsum && !(ATTN_DBG & 64)) {
     float sacc = 0.f;
 #pragma unroll 8
     for (int rr = 0; rr < 32; ++rr) sacc += (rr < rows_valid) ? bf2f(patch[rr * PS + lane]) : 0.f;
     colsum[lane] = accumulate ? colsum[lane] + sacc : sacc;
   }
+}
+
+// ---------------------------------------------------------------------------------------- staging
+// K / V (forward, dQ) and Q / dO (dK,dV) tiles reach LDS by LDS-DMA straight from global memory (global_load_lds, 1 KiB
+// per wave instruction): no staging registers, no ds_write, no per-tile address arithmetic. An image's swizzle is applied
+// to the per-lane SOURCE address; wave w writes rows [16w, 16w+16) of a 64-row image, 8 rows per instruction:
+//  row image (row_off): LDS (row, chunk') <- source chunk chunk' ^ ((row >> 1) & 7)
+//  tr image  (tr_off):  LDS 16-byte unit u of 256-byte sub-tile t <- source (row 4(t>>1) + (u>>2), col 32(t&1) + 8(u&3))
+// Two stages: the DMA of tile t+1 is issued when tile t starts and waited for (vmcnt) at the barrier that ends it.
+// DMA in the scalar-base form (global_load_lds v_offset, s[base:base+1]): the per-lane 32-bit byte offsets are lane
+// constants for the whole kernel and the tile's base address advances on the scalar unit — through the builtin hipcc
+// keeps one running 64-bit pointer per instruction in VGPRs (20 registers and a 64-bit VALU add each per tile here).
+// M0 = LDS byte address of the 1-KiB (256-B for the dword form) destination; one wait state after writing M0.
+typedef __attribute__((address_space(3))) char lds_char;
+#define LDS_ADDR(ptr) ((uint32_t)(uintptr_t)(lds_char*)(ptr))
+#define DMA16(sbase, voff, ldsaddr) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory", "m0")
+#define DMA4(sbase, voff, ldsaddr) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory", "m0")
+#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// lane constants of the staging: image rows / source columns (elements) of this lane's two instructions
+struct StageLane { int rA, cA0, cA1, rT, cT; };
+DEVI StageLane stage_lane(int wave, int lane) {
+  StageLane g;
+  g.rA = wave * 16 + (lane >> 3);
+  g.cA0 = ((lane & 7) ^ (lane >> 4)) * 8;
+  g.cA1 = ((lane & 7) ^ (4 + (lane >> 4))) * 8;
+  g.rT = wave * 16 + 4 * (lane >> 5) + ((lane & 15) >> 2);
+  g.cT = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  return g;
 }
 
 // ---------------------------------------------------------------------------------------- forward
@@ -111,7 +183,9 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
 #endif
 __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][2][64 * 64];  // [stage][K row | V tr] 32 KiB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DBG_EARLY_EXIT(p);
   // 1-D grid, XCD-aware: the q-tiles of one (batch, head) read the same K/V, so they get consecutive
   // logical ids = the same XCD's L2 (block id % 8 labels the XCD; placement affects speed only)
   const int QT = (p.S + 127) >> 7;
@@ -138,25 +212,29 @@ __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
   }
 
   const int nkt = (len + 63) >> 6;
-  const int sr = tid >> 3, sc = tid & 7;  // staging: 32 rows x 8 chunks, 2 passes
-  // staging registers are named scalars and every iteration loads/stores unconditionally (the
-  // last one re-loads its own tile): arrays captured by lambdas were demoted to scratch.
-  uint4 kr0, kr1, vr0, vr1;
-  const int so_r0 = row_off(sr, sc), so_r1 = row_off(sr + 32, sc);
-  const int so_t0 = tr_off(sr, sc * 8), so_t1 = tr_off(sr + 32, sc * 8);
-#define KV_LOAD(kt_)                                                        \
-  do {                                                                      \
-    int k0_ = (kt_) * 64 + sr, k1_ = k0_ + 32;                              \
-    k0_ = k0_ < S ? k0_ : S - 1; k1_ = k1_ < S ? k1_ : S - 1;               \
-    kr0 = *(const uint4*)(kbase + (tok0 + k0_) * ld + sc * 8);              \
-    kr1 = *(const uint4*)(kbase + (tok0 + k1_) * ld + sc * 8);              \
-    vr0 = *(const uint4*)(vbase + (tok0 + k0_) * ld + sc * 8);              \
-    vr1 = *(const uint4*)(vbase + (tok0 + k1_) * ld + sc * 8);              \
-  } while (0)
-#define KV_STORE(st_)                                                       \
-  do {                                                                      \
-    *(uint4*)&smem[st_][0][so_r0] = kr0; *(uint4*)&smem[st_][0][so_r1] = kr1; \
-    *(uint4*)&smem[st_][1][so_t0] = vr0; *(uint4*)&smem[st_][1][so_t1] = vr1; \
+  const StageLane g = stage_lane(wave, lane);
+  const uint32_t vA0 = (uint32_t)(g.rA * ld + g.cA0) * 2, vA1 = (uint32_t)((g.rA + 8) * ld + g.cA1) * 2;
+  const uint32_t vT = (uint32_t)(g.rT * ld + g.cT) * 2;
+  const uint32_t lds0 = LDS_ADDR(&smem[0][0][0]) + (uint32_t)wave * 2048;
+  const bf16_t* gk = kbase + tok0 * ld;
+  const bf16_t* gv = vbase + tok0 * ld;
+#define KV_STAGE(ST, kt_)                                                                                \
+  do {                                                                                                   \
+    const int k0_ = (kt_) * 64;                                                                          \
+    const uint32_t l_ = lds0 + (ST) * 16384;                                                             \
+    if (k0_ + 64 <= S) {                                                                                 \
+      const char* sk_ = (const char*)(gk + (size_t)k0_ * ld);                                            \
+      const char* sv_ = (const char*)(gv + (size_t)k0_ * ld);                                            \
+      DMA16(sk_, vA0, l_); DMA16(sk_, vA1, l_ + 1024);                                                   \
+      DMA16(sv_, vT, l_ + 8192); DMA16(sv_ + 16 * ld, vT, l_ + 8192 + 1024);                             \
+    } else { /* the tile that crosses S: rows are clamped, every lane computes its own offsets */        \
+      const int a0_ = min(k0_ + g.rA, S - 1), a1_ = min(k0_ + g.rA + 8, S - 1);                          \
+      const int t0_ = min(k0_ + g.rT, S - 1), t1_ = min(k0_ + g.rT + 8, S - 1);                          \
+      DMA16((const char*)gk, (uint32_t)(a0_ * ld + g.cA0) * 2, l_);                                      \
+      DMA16((const char*)gk, (uint32_t)(a1_ * ld + g.cA1) * 2, l_ + 1024);                               \
+      DMA16((const char*)gv, (uint32_t)(t0_ * ld + g.cT) * 2, l_ + 8192);                                \
+      DMA16((const char*)gv, (uint32_t)(t1_ * ld + g.cT) * 2, l_ + 8192 + 1024);                         \
+    }                                                                                                    \
   } while (0)
 
   f32x16 o0 = zero16(), o1 = zero16();
@@ -165,20 +243,20 @@ __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
 
   int kqo[4];
   row_frag_offsets(lane, kqo);
-  KV_LOAD(0);
-  KV_STORE(0);
+  KV_STAGE(0, 0);
+  DMA_WAIT();
   __syncthreads();
   // One tile of 64 keys out of LDS stage CUR (a literal: every LDS address below is a lane constant + an immediate; with
   // a run-time stage hipcc re-derived ~45 address VALU per tile in a VALU-bound loop). The loop runs two tiles per trip.
 #define FWD_TILE(CUR, kt)                                                                                         \
   do {                                                                                                            \
-    KV_LOAD((kt) + 1 < nkt ? (kt) + 1 : (kt));                                                                    \
+    if ((kt) + 1 < nkt) KV_STAGE((CUR) ^ 1, (kt) + 1);                                                            \
     const bf16_t* sK = smem[CUR][0];                                                                              \
     const bf16_t* sV = smem[CUR][1];                                                                              \
     f32x16 s0 = zero16(), s1 = zero16();                                                                          \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                            \
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ROW_FRAG(sK, 0, ks, kqo), qf[ks], s0, 0, 0, 0);                \
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ROW_FRAG(sK, 1, ks, kqo), qf[ks], s1, 0, 0, 0);                \
+      s0 = MFMA32(ROW_FRAG(sK, 0, ks, kqo), qf[ks], s0);                \
+      s1 = MFMA32(ROW_FRAG(sK, 1, ks, kqo), qf[ks], s1);                \
     }                                                                                                             \
     /* Softmax in the exp2 domain. The loop is VALU-bound at head_dim 64 (one v_exp per score against 256 MFMA */ \
     /* flops), so: masking only in a tile that crosses the length, the scale folded into one FMA per score (max */\
@@ -197,37 +275,36 @@ __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                       \
     const float m_new = fmaxf(m_run, mx * sl2); /* finite: the first tile always holds key 0 < len */             \
     if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {                                                       \
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                                                  \
+      const float alpha = EXP2(m_run - m_new);                                                  \
       l_run *= alpha;                                                                                             \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }                          \
       m_run = m_new;                                                                                              \
     }                                                                                                             \
     float ls = 0.f;                                                                                               \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
-      s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], sl2, -m_new));                                         \
-      s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], sl2, -m_new));                                         \
+      s0[r] = EXP2(__builtin_fmaf(s0[r], sl2, -m_new));                                         \
+      s1[r] = EXP2(__builtin_fmaf(s1[r], sl2, -m_new));                                         \
       ls += s0[r] + s1[r];                                                                                        \
     }                                                                                                             \
     l_run += ls;                                                                                                  \
     _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                            \
       const bf16x8 pb = acc_frag((s4 >> 1) ? s1 : s0, s4 & 1);                                                    \
-      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, s4 >> 1, s4 & 1, 0, lane), pb, o0, 0, 0, 0);       \
-      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sV, s4 >> 1, s4 & 1, 1, lane), pb, o1, 0, 0, 0);       \
+      o0 = MFMA32(tr_frag(sV, s4 >> 1, s4 & 1, 0, lane), pb, o0);       \
+      o1 = MFMA32(tr_frag(sV, s4 >> 1, s4 & 1, 1, lane), pb, o1);       \
     }                                                                                                             \
-    KV_STORE((CUR) ^ 1);                                                                                          \
-    __syncthreads();                                                                                              \
+    DMA_WAIT();                                                                                                   \
+    TILE_SYNC();                                                                                                 \
   } while (0)
-  for (int kt = 0; kt < nkt; kt += 2) {
+  for (int kt = 0; kt < DBG_TILES(nkt); kt += 2) {
     FWD_TILE(0, kt);
     if (kt + 1 < nkt) FWD_TILE(1, kt + 1);
   }
 #undef FWD_TILE
-#undef KV_LOAD
-#undef KV_STORE
+#undef KV_STAGE
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
   if (h == 0 && q0 + lq < S)
-    p.lse[((size_t)b * p.NH + hd) * S + q0 + lq] = m_run * LN2 + __logf(l_tot);
+    p.lse[((size_t)b * p.NH + hd) * S + q0 + lq] = -(m_run + __log2f(l_tot)) / sl2;  // see PlbAttn.lse
   // all waves are past the last barrier: reuse the staging LDS as per-wave transpose patches
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
   int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
@@ -238,7 +315,9 @@ __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
 // ------------------------------------------------------------------------------------- backward dQ
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][3][64 * 64];  // [stage][K row | K tr | V row] 48 KiB
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DBG_EARLY_EXIT(p);
   // 1-D grid, XCD-aware: the q-tiles of one (batch, head) read the same K/V, so they get consecutive
   // logical ids = the same XCD's L2 (block id % 8 labels the XCD; placement affects speed only)
   const int QT = (p.S + 127) >> 7;
@@ -275,75 +354,86 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
   }
   const size_t stat = ((size_t)b * p.NH + hd) * S + qr;
   if (h == 0 && q0 + lq < S) p.delta[stat] = delta;
-  const float lse2 = p.lse[stat] * LOG2E;
+  const float lse2 = p.lse[stat] * (p.scale * LOG2E);  // stored as -LSE in raw-score units (PlbAttn.lse)
   const float sl2 = p.scale * LOG2E;
 
   const int nkt = (len + 63) >> 6;
-  const int sr = tid >> 3, sc = tid & 7;
-  uint4 kr0, kr1, vr0, vr1;
-  const int so_r0 = row_off(sr, sc), so_r1 = row_off(sr + 32, sc);
-  const int so_t0 = tr_off(sr, sc * 8), so_t1 = tr_off(sr + 32, sc * 8);
-#define KV_LOAD(kt_)                                                        \
-  do {                                                                      \
-    int k0_ = (kt_) * 64 + sr, k1_ = k0_ + 32;                              \
-    k0_ = k0_ < S ? k0_ : S - 1; k1_ = k1_ < S ? k1_ : S - 1;               \
-    kr0 = *(const uint4*)(kbase + (tok0 + k0_) * ld + sc * 8);              \
-    kr1 = *(const uint4*)(kbase + (tok0 + k1_) * ld + sc * 8);              \
-    vr0 = *(const uint4*)(vbase + (tok0 + k0_) * ld + sc * 8);              \
-    vr1 = *(const uint4*)(vbase + (tok0 + k1_) * ld + sc * 8);              \
-  } while (0)
-#define KV_STORE(st_)                                                       \
-  do {                                                                      \
-    *(uint4*)&smem[st_][0][so_r0] = kr0; *(uint4*)&smem[st_][0][so_r1] = kr1; \
-    *(uint4*)&smem[st_][1][so_t0] = kr0; *(uint4*)&smem[st_][1][so_t1] = kr1; \
-    *(uint4*)&smem[st_][2][so_r0] = vr0; *(uint4*)&smem[st_][2][so_r1] = vr1; \
+  const StageLane g = stage_lane(wave, lane);
+  const uint32_t vA0 = (uint32_t)(g.rA * ld + g.cA0) * 2, vA1 = (uint32_t)((g.rA + 8) * ld + g.cA1) * 2;
+  const uint32_t vT = (uint32_t)(g.rT * ld + g.cT) * 2;
+  const uint32_t lds0 = LDS_ADDR(&smem[0][0][0]) + (uint32_t)wave * 2048;
+  const bf16_t* gk = kbase + tok0 * ld;
+  const bf16_t* gv = vbase + tok0 * ld;
+  // [K row | K tr | V row]: the V row image takes the K row image's lane offsets from V's base
+#define KV_STAGE(ST, kt_)                                                                                \
+  do {                                                                                                   \
+    const int k0_ = (kt_) * 64;                                                                          \
+    const uint32_t l_ = lds0 + (ST) * 24576;                                                             \
+    if (k0_ + 64 <= S) {                                                                                 \
+      const char* sk_ = (const char*)(gk + (size_t)k0_ * ld);                                            \
+      const char* sv_ = (const char*)(gv + (size_t)k0_ * ld);                                            \
+      DMA16(sk_, vA0, l_); DMA16(sk_, vA1, l_ + 1024);                                                   \
+      DMA16(sk_, vT, l_ + 8192); DMA16(sk_ + 16 * ld, vT, l_ + 8192 + 1024);                             \
+      DMA16(sv_, vA0, l_ + 16384); DMA16(sv_, vA1, l_ + 16384 + 1024);                                   \
+    } else { /* the tile that crosses S: rows are clamped, every lane computes its own offsets */        \
+      const int a0_ = min(k0_ + g.rA, S - 1), a1_ = min(k0_ + g.rA + 8, S - 1);                          \
+      const int t0_ = min(k0_ + g.rT, S - 1), t1_ = min(k0_ + g.rT + 8, S - 1);                          \
+      const uint32_t va0_ = (uint32_t)(a0_ * ld + g.cA0) * 2, va1_ = (uint32_t)(a1_ * ld + g.cA1) * 2;  \
+      DMA16((const char*)gk, va0_, l_); DMA16((const char*)gk, va1_, l_ + 1024);                         \
+      DMA16((const char*)gk, (uint32_t)(t0_ * ld + g.cT) * 2, l_ + 8192);                                \
+      DMA16((const char*)gk, (uint32_t)(t1_ * ld + g.cT) * 2, l_ + 8192 + 1024);                         \
+      DMA16((const char*)gv, va0_, l_ + 16384); DMA16((const char*)gv, va1_, l_ + 16384 + 1024);         \
+    }                                                                                                    \
   } while (0)
 
   f32x16 dq0 = zero16(), dq1 = zero16();
-  KV_LOAD(0);
-  KV_STORE(0);
+  int kro[4];
+  row_frag_offsets(lane, kro);
+  KV_STAGE(0, 0);
+  DMA_WAIT();
   __syncthreads();
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int cur = kt & 1;
-    KV_LOAD(kt + 1 < nkt ? kt + 1 : kt);
-    const bf16_t* sK = smem[cur][0];
-    const bf16_t* sKt = smem[cur][1];
-    const bf16_t* sV = smem[cur][2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      // row constants as the initial accumulator: the query sits on the lane, so dP starts at -delta and the
-      // MFMA chain leaves dP - delta ready (one VALU less per score)
-      f32x16 s = zero16(), dp = splat16(-delta);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sK, kb, ks, lane), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sV, kb, ks, lane), dof[ks], dp, 0, 0, 0);
-      }
-      const int kb0 = kt * 64 + kb * 32 + 4 * h;
-      if (kt * 64 + 64 > len) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kb0 + (r & 3) + 8 * (r >> 2);
-          s[r] = (key < len) ? s[r] : -INFINITY;   // exp2(-inf) = 0
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -lse2));
-        s[r] = pr * dp[r];   // dS^T = P (dP - delta); the scale is applied once at the end
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const bf16x8 dsb = acc_frag(s, s2);
-        dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sKt, kb, s2, 0, lane), dsb, dq0, 0, 0, 0);
-        dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sKt, kb, s2, 1, lane), dsb, dq1, 0, 0, 0);
-      }
-    }
-    KV_STORE(cur ^ 1);
-    __syncthreads();
+  // One tile of 64 keys out of LDS stage CUR (a literal, as in the forward: every LDS address is a lane constant + an
+  // immediate). Row constants as the initial accumulator: the query sits on the lane, so dP starts at -delta and the MFMA
+  // chain leaves dP - delta ready (one VALU less per score).
+#define DQ_TILE(CUR, kt_)                                                                                 \
+  do {                                                                                                    \
+    const int kt = (kt_);                                                                                 \
+    if (kt + 1 < nkt) KV_STAGE((CUR) ^ 1, kt + 1);                                                        \
+    const bf16_t* sK = smem[CUR][0];                                                                      \
+    const bf16_t* sKt = smem[CUR][1];                                                                     \
+    const bf16_t* sV = smem[CUR][2];                                                                      \
+    _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                    \
+      f32x16 s = zero16(), dp = splat16(-delta);                                                          \
+      _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                  \
+        s = MFMA32(ROW_FRAG(sK, kb, ks, kro), qf[ks], s);                                                 \
+        dp = MFMA32(ROW_FRAG(sV, kb, ks, kro), dof[ks], dp);                                              \
+      }                                                                                                   \
+      if (kt * 64 + 64 > len) {                                                                           \
+        const int kb0 = kt * 64 + kb * 32 + 4 * h;                                                        \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
+          const int key = kb0 + (r & 3) + 8 * (r >> 2);                                                   \
+          s[r] = (key < len) ? s[r] : -INFINITY; /* exp2(-inf) = 0 */                                     \
+        }                                                                                                 \
+      }                                                                                                   \
+      _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                    \
+        const float pr = EXP2(__builtin_fmaf(s[r], sl2, lse2));                                           \
+        s[r] = pr * dp[r]; /* dS^T = P (dP - delta); the scale is applied once at the end */              \
+      }                                                                                                   \
+      _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                  \
+        const bf16x8 dsb = acc_frag(s, s2);                                                               \
+        dq0 = MFMA32(tr_frag(sKt, kb, s2, 0, lane), dsb, dq0);                                            \
+        dq1 = MFMA32(tr_frag(sKt, kb, s2, 1, lane), dsb, dq1);                                            \
+      }                                                                                                   \
+    }                                                                                                     \
+    DMA_WAIT();                                                                                           \
+    TILE_SYNC();                                                                                          \
+  } while (0)
+  for (int kt2 = 0; kt2 < DBG_TILES(nkt); kt2 += 2) {
+    DQ_TILE(0, kt2);
+    if (kt2 + 1 < nkt) DQ_TILE(1, kt2 + 1);
   }
-#undef KV_LOAD
-#undef KV_STORE
+#undef DQ_TILE
+#undef KV_STAGE
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
   int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
   // bias-gradient partial row of this wave: [(b * QT + q tile) * 4 + wave][3H], columns hd*64.. of the Q block
@@ -355,11 +445,20 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
 }
 
 // ---------------------------------------------------------------------------------- backward dK,dV
+// A wave owns 32 keys (K, V fragments in registers, dK^T / dV^T accumulators) and walks the query tiles of its (batch,
+// head). A query tile = four 8-KiB LDS images (Q and dO, each as a row image for the S / dP products and as a transposed-
+// read image for dV^T = dO^T·P and dK^T = Q^T·dS) plus the 64 row statistics (log2-domain LSE, delta), all written by
+// LDS-DMA straight from global memory (global_load_lds, 1 KiB per wave instruction, the images' swizzles applied to the
+// per-lane SOURCE address): no staging registers, no ds_write, no per-tile address arithmetic beyond one 64-bit add per
+// instruction. Two stages: the DMA of tile t+1 is issued when tile t starts and waited for at the barrier that ends it.
+
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   // [stage][Q row | Q tr | dO row | dO tr] + lse/delta rows
   __shared__ __attribute__((aligned(16))) bf16_t smem[2][4][64 * 64];  // 64 KiB
-  __shared__ __attribute__((aligned(16))) float sstat[2][2][64];       // [stage][lse*log2e | delta][q]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) float sstat[2][2][64];       // [stage][lse (log2 domain) | delta][q]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DBG_EARLY_EXIT(p);
   const int QT = (p.S + 127) >> 7;  // key tiles of one (batch, head) share Q / dO: same XCD
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int bx = logical % QT, bh = logical / QT;
@@ -369,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   len = len < 1 ? 1 : (len > S ? S : len);
   const int key0 = bx * 128 + wave * 32;
   const size_t tok0 = (size_t)b * S;
-  const int ld = p.ldqkv;
+  const int ld = p.ldqkv, ldo = p.lddctx;
   const int lk = lane & 31, h = lane >> 5;
   const int mykey = key0 + lk;
 
@@ -389,89 +488,131 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
 
   // queries past the length carry exactly zero dO in this model (no loss there), so tiles stop at len
   const int nqt = (bx * 128 < len) ? ((len + 63) >> 6) : 0;
-  const int sr = tid >> 3, sc = tid & 7;
-  uint4 qr0, qr1, dr0, dr1;
-  float st_l = 0.f, st_d = 0.f;
-  const bf16_t* qbase = p.qkv + hd * 64;
-  const bf16_t* dobase = p.dctx + hd * 64;
-  const size_t statb = ((size_t)b * p.NH + hd) * S;
-  const int so_r0 = row_off(sr, sc), so_r1 = row_off(sr + 32, sc);
-  const int so_t0 = tr_off(sr, sc * 8), so_t1 = tr_off(sr + 32, sc * 8);
-  const int stq = tid & 63;  // every wave loads the 64 row statistics; wave 0 stores them
-#define Q_LOAD(qt_)                                                         \
-  do {                                                                      \
-    int q0_ = (qt_) * 64 + sr, q1_ = q0_ + 32;                              \
-    q0_ = q0_ < S ? q0_ : S - 1; q1_ = q1_ < S ? q1_ : S - 1;               \
-    qr0 = *(const uint4*)(qbase + (tok0 + q0_) * ld + sc * 8);              \
-    qr1 = *(const uint4*)(qbase + (tok0 + q1_) * ld + sc * 8);              \
-    dr0 = *(const uint4*)(dobase + (tok0 + q0_) * p.lddctx + sc * 8);       \
-    dr1 = *(const uint4*)(dobase + (tok0 + q1_) * p.lddctx + sc * 8);       \
-    int qs_ = (qt_) * 64 + stq; qs_ = qs_ < S ? qs_ : S - 1;                \
-    st_l = p.lse[statb + qs_] * LOG2E;                                      \
-    st_d = p.delta[statb + qs_];                                            \
-  } while (0)
-#define Q_STORE(st_)                                                        \
-  do {                                                                      \
-    *(uint4*)&smem[st_][0][so_r0] = qr0; *(uint4*)&smem[st_][0][so_r1] = qr1; \
-    *(uint4*)&smem[st_][1][so_t0] = qr0; *(uint4*)&smem[st_][1][so_t1] = qr1; \
-    *(uint4*)&smem[st_][2][so_r0] = dr0; *(uint4*)&smem[st_][2][so_r1] = dr1; \
-    *(uint4*)&smem[st_][3][so_t0] = dr0; *(uint4*)&smem[st_][3][so_t1] = dr1; \
-    if (tid < 64) { sstat[st_][0][tid] = st_l; sstat[st_][1][tid] = st_d; }  \
+  const bf16_t* gq = p.qkv + hd * 64 + tok0 * ld;
+  const bf16_t* gdo = p.dctx + hd * 64 + tok0 * ldo;
+  const float* glse = p.lse + ((size_t)b * p.NH + hd) * S;
+  const float* gdelta = p.delta + ((size_t)b * p.NH + hd) * S;
+  // staging: this wave writes rows [16w, 16w+16) of every image, 8 rows (1 KiB) per instruction.
+  //  row image  (row_off):  LDS (row, chunk') <- source chunk chunk' ^ ((row >> 1) & 7)
+  //  tr image   (tr_off):   LDS 16-byte unit u of 256-byte sub-tile t <- source (row 4(t>>1) + (u>>2), col 32(t&1) + 8(u&3))
+  const int rA = wave * 16 + (lane >> 3);
+  const int cA0 = ((lane & 7) ^ (lane >> 4)) * 8, cA1 = ((lane & 7) ^ (4 + (lane >> 4))) * 8;
+  const int rT = wave * 16 + 4 * (lane >> 5) + ((lane & 15) >> 2);
+  const int cT = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  // byte offsets from the tile's first row; the second instruction of an image is 8 rows further (the row image also
+  // changes its swizzled column, so it has its own offset; the tr image uses the scalar base + 8 rows)
+  const uint32_t vqA0 = (uint32_t)(rA * ld + cA0) * 2, vqA1 = (uint32_t)((rA + 8) * ld + cA1) * 2, vqT = (uint32_t)(rT * ld + cT) * 2;
+  const uint32_t vdA0 = (uint32_t)(rA * ldo + cA0) * 2, vdA1 = (uint32_t)((rA + 8) * ldo + cA1) * 2, vdT = (uint32_t)(rT * ldo + cT) * 2;
+  const uint32_t vst = (uint32_t)lane * 4;
+  const uint32_t lds0 = LDS_ADDR(&smem[0][0][0]) + (uint32_t)wave * 2048, ldst = LDS_ADDR(&sstat[0][0][0]);
+#define DKV_STAGE(ST, qt_)                                                                              \
+  do {                                                                                                  \
+    const int q0_ = (qt_) * 64;                                                                         \
+    const uint32_t l_ = lds0 + (ST) * 32768;                                                            \
+    if (q0_ + 64 <= S) {                                                                                \
+      const char* sq_ = (const char*)(gq + (size_t)q0_ * ld);                                           \
+      const char* sd_ = (const char*)(gdo + (size_t)q0_ * ldo);                                         \
+      const char* sq8_ = sq_ + 16 * ld;                                                                 \
+      const char* sd8_ = sd_ + 16 * ldo;                                                                \
+      DMA16(sq_, vqA0, l_); DMA16(sq_, vqA1, l_ + 1024);                                                \
+      DMA16(sq_, vqT, l_ + 8192); DMA16(sq8_, vqT, l_ + 8192 + 1024);                                   \
+      DMA16(sd_, vdA0, l_ + 16384); DMA16(sd_, vdA1, l_ + 16384 + 1024);                                \
+      DMA16(sd_, vdT, l_ + 24576); DMA16(sd8_, vdT, l_ + 24576 + 1024);                                 \
+      if (wave == 0) DMA4((const char*)(glse + q0_), vst, ldst + (ST) * 512);                           \
+      if (wave == 1) DMA4((const char*)(gdelta + q0_), vst, ldst + (ST) * 512 + 256);                   \
+    } else { /* the tile that crosses S: rows are clamped, every lane computes its own offsets */       \
+      const int a0_ = min(q0_ + rA, S - 1), a1_ = min(q0_ + rA + 8, S - 1);                             \
+      const int t0_ = min(q0_ + rT, S - 1), t1_ = min(q0_ + rT + 8, S - 1);                             \
+      const char* sq_ = (const char*)gq;                                                                \
+      const char* sd_ = (const char*)gdo;                                                               \
+      DMA16(sq_, (uint32_t)(a0_ * ld + cA0) * 2, l_); DMA16(sq_, (uint32_t)(a1_ * ld + cA1) * 2, l_ + 1024);                  \
+      DMA16(sq_, (uint32_t)(t0_ * ld + cT) * 2, l_ + 8192); DMA16(sq_, (uint32_t)(t1_ * ld + cT) * 2, l_ + 8192 + 1024);      \
+      DMA16(sd_, (uint32_t)(a0_ * ldo + cA0) * 2, l_ + 16384); DMA16(sd_, (uint32_t)(a1_ * ldo + cA1) * 2, l_ + 16384 + 1024); \
+      DMA16(sd_, (uint32_t)(t0_ * ldo + cT) * 2, l_ + 24576); DMA16(sd_, (uint32_t)(t1_ * ldo + cT) * 2, l_ + 24576 + 1024);   \
+      const uint32_t vs_ = (uint32_t)min(q0_ + lane, S - 1) * 4;                                        \
+      if (wave == 0) DMA4((const char*)glse, vs_, ldst + (ST) * 512);                                   \
+      if (wave == 1) DMA4((const char*)gdelta, vs_, ldst + (ST) * 512 + 256);                           \
+    }                                                                                                   \
   } while (0)
 
+  int roff[4];
+  row_frag_offsets(lane, roff);
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
-  if (nqt > 0) { Q_LOAD(0); Q_STORE(0); }
+  if (nqt > 0) DKV_STAGE(0, 0);
+  DMA_WAIT();
   __syncthreads();
-  for (int qt = 0; qt < nqt; ++qt) {
-    const int cur = qt & 1;
-    Q_LOAD(qt + 1 < nqt ? qt + 1 : qt);
-    const bf16_t* sQ = smem[cur][0];
-    const bf16_t* sQt = smem[cur][1];
-    const bool need_mask = (key0 + 32 > len) || (qt * 64 + 64 > len);  // wave-uniform
-    const bf16_t* sDO = smem[cur][2];
-    const bf16_t* sDOt = smem[cur][3];
-    // The tile body exists twice: tiles that cross the length (of keys or of queries) mask, all the others run
-    // without a single compare / select — written as one select on a wave-uniform flag, hipcc if-converted the mask
-    // into every tile (32 v_cmp + 32 v_cndmask + 66 scalar mask ops per tile of a VALU-bound loop).
-    // Row constants as initial accumulators: dP starts at -delta[q] (q runs over the registers here), so the MFMA
-    // chain leaves dP - delta.
-#define DKV_TILE(MASK)                                                                                          \
-  _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                                            \
-    f32x16 s = zero16(), dp;                                                                                    \
-    float lv[16];                                                                                               \
+  // One tile out of stage CUR (a literal: every LDS address is a lane constant + an immediate). The tile body exists
+  // twice more: tiles that cross the length (of keys or of queries) mask, all the others run without a single compare /
+  // select — written as one select on a wave-uniform flag, hipcc if-converted the mask into every tile.
+  // Row constants as initial accumulators: dP starts at -delta[q] (q runs over the registers here), so the MFMA chain
+  // leaves dP - delta. Per 32-query block: statistics and the 8 row fragments are read, 8 MFMAs (S, dP), then the 8
+  // transposed fragments of the second products are requested BEFORE the softmax arithmetic so they land under it.
+#define DKV_BLOCK(CUR, MASK, qb)                                                                                \
+  {                                                                                                             \
+    f32x16 s, dp;                                                                                               \
     _Pragma("unroll") for (int rg = 0; rg < 4; ++rg) {                                                          \
-      const int ql = qb * 32 + 8 * rg + 4 * h;                                                                  \
-      const float4 l4 = *(const float4*)&sstat[cur][0][ql];                                                     \
-      const float4 d4 = *(const float4*)&sstat[cur][1][ql];                                                     \
-      lv[4 * rg + 0] = l4.x; lv[4 * rg + 1] = l4.y; lv[4 * rg + 2] = l4.z; lv[4 * rg + 3] = l4.w;               \
+      const int ql = (qb) * 32 + 8 * rg + 4 * h;                                                                \
+      const float4 l4 = *(const float4*)&sstat[CUR][0][ql];                                                     \
+      const float4 d4 = *(const float4*)&sstat[CUR][1][ql];                                                     \
+      s[4 * rg + 0] = l4.x; s[4 * rg + 1] = l4.y; s[4 * rg + 2] = l4.z; s[4 * rg + 3] = l4.w;                   \
       dp[4 * rg + 0] = -d4.x; dp[4 * rg + 1] = -d4.y; dp[4 * rg + 2] = -d4.z; dp[4 * rg + 3] = -d4.w;           \
     }                                                                                                           \
+    bf16x8 fq[4], fd[4];                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                          \
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sQ, qb, ks, lane), kf[ks], s, 0, 0, 0);              \
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(sDO, qb, ks, lane), vf[ks], dp, 0, 0, 0);           \
+      fq[ks] = ROW_FRAG(smem[CUR][0], qb, ks, roff);                                                            \
+      fd[ks] = ROW_FRAG(smem[CUR][2], qb, ks, roff);                                                            \
     }                                                                                                           \
-    /* s[r] = S[q][key]: key on the lane, q = qt*64 + qb*32 + (r&3) + 8(r>>2) + 4h; dS overwrites dP */         \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                          \
+      s = MFMA32(fq[ks], kf[ks], s);                                                                            \
+      dp = MFMA32(fd[ks], vf[ks], dp);                                                                          \
+    }                                                                                                           \
+    bf16x8 tdo[2][2], tq[2][2];                                                                                 \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                            \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) tdo[s2][cb] = tr_frag(smem[CUR][3], qb, s2, cb, lane);   \
+    ;                                                                                                           \
+    /* s[r] = S[q][key] - LSE: key on the lane, q = qt*64 + qb*32 + (r&3) + 8(r>>2) + 4h */                     \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                            \
-      float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], sl2, -lv[r]));                                     \
-      if (MASK) pr = (key_ok && (qt * 64 + qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < len)) ? pr : 0.f;         \
+      float pr = EXP2(s[r] * sl2);                                                                              \
+      if (MASK) pr = (key_ok && (qt * 64 + (qb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < len)) ? pr : 0.f;       \
       s[r] = pr;                                                                                                \
-      dp[r] = pr * dp[r];                                                                                       \
     }                                                                                                           \
-    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2) {                                                          \
-      const bf16x8 pb = acc_frag(s, s2), dsb = acc_frag(dp, s2);                                                \
-      dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDOt, qb, s2, 0, lane), pb, dv0, 0, 0, 0);          \
-      dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sDOt, qb, s2, 1, lane), pb, dv1, 0, 0, 0);          \
-      dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQt, qb, s2, 0, lane), dsb, dk0, 0, 0, 0);          \
-      dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(sQt, qb, s2, 1, lane), dsb, dk1, 0, 0, 0);          \
+    _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                            \
+      _Pragma("unroll") for (int cb = 0; cb < 2; ++cb) tq[s2][cb] = tr_frag(smem[CUR][1], qb, s2, cb, lane);    \
+    {                                                                                                           \
+      const bf16x8 pb0 = acc_frag(s, 0), pb1 = acc_frag(s, 1);                                                  \
+      dv0 = MFMA32(tdo[0][0], pb0, dv0);                                                                        \
+      dv1 = MFMA32(tdo[0][1], pb0, dv1);                                                                        \
+      dv0 = MFMA32(tdo[1][0], pb1, dv0);                                                                        \
+      dv1 = MFMA32(tdo[1][1], pb1, dv1);                                                                        \
     }                                                                                                           \
+    /* dS = P (dP - delta) overwrites dP while the dV MFMAs run */                                              \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) dp[r] = s[r] * dp[r];                                        \
+    {                                                                                                           \
+      const bf16x8 ds0 = acc_frag(dp, 0), ds1 = acc_frag(dp, 1);                                                \
+      dk0 = MFMA32(tq[0][0], ds0, dk0);                                                                         \
+      dk1 = MFMA32(tq[0][1], ds0, dk1);                                                                         \
+      dk0 = MFMA32(tq[1][0], ds1, dk0);                                                                         \
+      dk1 = MFMA32(tq[1][1], ds1, dk1);                                                                         \
+    }                                                                                                           \
+    ;                                                                                                           \
   }
-    if (need_mask) { DKV_TILE(true) } else { DKV_TILE(false) }
+#define DKV_TILE(CUR, qt_)                                                                                      \
+  do {                                                                                                          \
+    const int qt = (qt_);                                                                                       \
+    if (qt + 1 < nqt) DKV_STAGE((CUR) ^ 1, qt + 1);                                                             \
+    const bool need_mask = (key0 + 32 > len) || (qt * 64 + 64 > len); /* wave-uniform */                        \
+    if (need_mask) { DKV_BLOCK(CUR, true, 0) DKV_BLOCK(CUR, true, 1) }                                          \
+    else { DKV_BLOCK(CUR, false, 0) DKV_BLOCK(CUR, false, 1) }                                                  \
+    DMA_WAIT();                                                                                                 \
+    TILE_SYNC();                                                                                                \
+  } while (0)
+  for (int qt2 = 0; qt2 < DBG_TILES(nqt); qt2 += 2) {
+    DKV_TILE(0, qt2);
+    if (qt2 + 1 < nqt) DKV_TILE(1, qt2 + 1);
+  }
 #undef DKV_TILE
-    Q_STORE(cur ^ 1);
-    __syncthreads();
-  }
-#undef Q_LOAD
-#undef Q_STORE
+#undef DKV_BLOCK
+#undef DKV_STAGE
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
   int rows_valid = S - key0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
   float* cp = p.colpart ? p.colpart + ((size_t)(b * QT + bx) * 4 + wave) * (3 * H) + hd * 64 : nullptr;

@@ -135,7 +135,7 @@ typedef struct {
   int B, S, NH, H;
   float scale;                  // head_dim^-0.5
   bf16_t* ctx; int ldctx;       // [T,H]
-  float* lse;                   // [B,NH,S]
+  float* lse;                   // [B,NH,S] MINUS the log-sum-exp of the scaled scores, in units of RAW scores (-lse/scale): the backward starts its S accumulators there
   // backward
   const bf16_t* dctx; int lddctx;
   float* delta;                 // [B,NH,S]
