@@ -289,7 +289,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   const int64_t Ls = tr ? L : 1;  // layers of activations kept
   e->Tcap = Tp;
   e->NMcap = Tp;
-  e->ln_blocks = 1024;
+  e->ln_blocks = 512;  // LayerNorm-backward partial rows: 512 workgroups measured best at both model widths (tools/ln_bench.py --blocks)
   e->emb_blocks = 2048;
   Carve cv;
   // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 from plbert_amd import _lib  # noqa: E402
 
 
-def bench(L, T, H, iters=50):
+def bench(L, T, H, iters=50, nb=1024):
     dev = "cuda"
     x = torch.randn(T, H, device=dev).to(torch.bfloat16)
     dy = torch.randn(T, H, device=dev).to(torch.bfloat16)
@@ -19,7 +19,6 @@ def bench(L, T, H, iters=50):
     dx = torch.empty_like(x)
     g, b = torch.randn(H, device=dev), torch.randn(H, device=dev)
     mean, rstd = torch.empty(T, device=dev), torch.empty(T, device=dev)
-    nb = 1024
     part = torch.empty(nb, 3 * H, device=dev)
     p = _lib.PlbLayerNorm()
     p.x, p.ldx, p.gamma, p.beta, p.eps = x.data_ptr(), H, g.data_ptr(), b.data_ptr(), 1e-12
@@ -45,6 +44,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--libs", default="")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--blocks", type=lambda v: [int(x) for x in v.split(",")], default=[1024],
+                    help="partial-sum blocks of the backward (the engine uses 1024)")
     args = ap.parse_args()
     libs = [("main", _lib.lib())]
     for path in [q for q in args.libs.split(",") if q]:
@@ -53,12 +54,13 @@ def main():
     for rep in range(args.reps):
         for (T, H) in ((16384, 768), (8192, 1024)):
             for name, L in libs:
-                (f_us, f_tb), (b_us, b_tb) = bench(L, T, H)
-                res.setdefault((name, T, H), []).append((f_us, b_us))
+                for nb in args.blocks:
+                    (f_us, f_tb), (b_us, b_tb) = bench(L, T, H, nb=nb)
+                    res.setdefault((f"{name}/{nb}", T, H), []).append((f_us, b_us))
     for (name, T, H), v in res.items():
         f = sorted(x[0] for x in v)[len(v) // 2]
         b = sorted(x[1] for x in v)[len(v) // 2]
-        print(f"{name:16s} T {T:6d} H {H:5d}  fwd {f:7.2f} us ({T*H*4/f/1e6:5.2f} TB/s)   bwd {b:7.2f} us ({T*H*6/b/1e6:5.2f} TB/s)", flush=True)
+        print(f"{name:22s} T {T:6d} H {H:5d}  fwd {f:7.2f} us ({T*H*4/f/1e6:5.2f} TB/s)   bwd {b:7.2f} us ({T*H*6/b/1e6:5.2f} TB/s)", flush=True)
 
 
 if __name__ == "__main__":
