@@ -178,6 +178,9 @@ DEVI StageLane stage_lane(int wave, int lane) {
 }
 
 // ---------------------------------------------------------------------------------------- forward
+#ifndef RESCALE_TH
+#define RESCALE_TH 8.0f  // the forward rescales its accumulators when a row maximum grows by more than this (log2 units)
+#endif
 #ifndef FWD_WAVES
 #define FWD_WAVES 3   // waves per SIMD the register allocation is held to
 #endif
@@ -261,8 +264,13 @@ __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
     /* Softmax in the exp2 domain. The loop is VALU-bound at head_dim 64 (one v_exp per score against 256 MFMA */ \
     /* flops), so: masking only in a tile that crosses the length, the scale folded into one FMA per score (max */\
     /* taken on raw scores: the scale is positive), the row maximum as a chain of three-input maxima, and the */   \
-    /* accumulator rescaled only when some query's running max actually moved (exact: alpha == 1 otherwise). */   \
+    /* accumulator rescaled only when some query's running max has moved by more than RESCALE_TH (log2 units): below */ \
+    /* that the stale maximum stays the reference — probabilities up to 2^TH instead of 1, harmless in fp32 / bf16, */ \
+    /* and LSE = m_run + log2(l) holds for any reference. Both conditionals carry an empty asm statement: without it */ \
+    /* hipcc if-converts them, and the 97 compare / select / index VALU of the mask and the 16 packed multiplies of */  \
+    /* the rescale then run in EVERY tile of a loop whose SIMDs are VALU-busy 61 % of the time (SQ_ACTIVE_INST_VALU). */ \
     if ((kt) * 64 + 64 > len) {                                                                                   \
+      asm volatile("; tile crosses the length");                                                                  \
       const int kbase_i = (kt) * 64 + 4 * h;                                                                      \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                            \
         const int kr0 = kbase_i + (r & 3) + 8 * (r >> 2);                                                         \
@@ -274,19 +282,20 @@ __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
     _Pragma("unroll") for (int r = 1; r < 16; ++r) mx = __builtin_fmaxf(__builtin_fmaxf(mx, s0[r]), s1[r]);       \
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                                       \
     const float m_new = fmaxf(m_run, mx * sl2); /* finite: the first tile always holds key 0 < len */             \
-    if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {                                                       \
+    if (__builtin_amdgcn_ballot_w64(m_new > m_run + RESCALE_TH) != 0) { /* first tile: m_run = -inf */            \
+      asm volatile("; rescale");                                                                                  \
       const float alpha = EXP2(m_run - m_new);                                                  \
       l_run *= alpha;                                                                                             \
       _Pragma("unroll") for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }                          \
       m_run = m_new;                                                                                              \
     }                                                                                                             \
-    float ls = 0.f;                                                                                               \
+    f32x2_t ls2 = {0.f, 0.f}; /* row sums as packed adds: one v_pk_add_f32 per pair of scores */                  \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                              \
-      s0[r] = EXP2(__builtin_fmaf(s0[r], sl2, -m_new));                                         \
-      s1[r] = EXP2(__builtin_fmaf(s1[r], sl2, -m_new));                                         \
-      ls += s0[r] + s1[r];                                                                                        \
+      s0[r] = EXP2(__builtin_fmaf(s0[r], sl2, -m_run));                                         \
+      s1[r] = EXP2(__builtin_fmaf(s1[r], sl2, -m_run));                                         \
+      ls2 += f32x2_t{s0[r], s1[r]};                                                                               \
     }                                                                                                             \
-    l_run += ls;                                                                                                  \
+    l_run += ls2[0] + ls2[1];                                                                                     \
     _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4) {                                                            \
       const bf16x8 pb = acc_frag((s4 >> 1) ? s1 : s0, s4 & 1);                                                    \
       o0 = MFMA32(tr_frag(sV, s4 >> 1, s4 & 1, 0, lane), pb, o0);       \
@@ -409,6 +418,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
         dp = MFMA32(ROW_FRAG(sV, kb, ks, kro), dof[ks], dp);                                              \
       }                                                                                                   \
       if (kt * 64 + 64 > len) {                                                                           \
+        asm volatile("; tile crosses the length"); /* keeps the branch: see the forward */                \
         const int kb0 = kt * 64 + kb * 32 + 4 * h;                                                        \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                  \
           const int key = kb0 + (r & 3) + 8 * (r >> 2);                                                   \
