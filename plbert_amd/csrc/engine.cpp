@@ -289,7 +289,9 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   const int64_t Ls = tr ? L : 1;  // layers of activations kept
   e->Tcap = Tp;
   e->NMcap = Tp;
-  e->ln_blocks = 512;  // LayerNorm-backward partial rows: 512 workgroups measured best at both model widths (tools/ln_bench.py --blocks)
+  // LayerNorm-backward partial rows (tools/ln_bench.py --blocks): at H = 1024 512 workgroups are 22 % faster than 1024
+  // (12.1 vs 15.5 us standalone); at H = 768 they measure 2 % faster alone and 4 % slower inside the step
+  e->ln_blocks = H >= 1024 ? 512 : 1024;
   e->emb_blocks = 2048;
   Carve cv;
   // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes
