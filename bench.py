@@ -426,7 +426,9 @@ def main():
     staged = None
     if not args.no_staged and not args.num_tokens and not shared:  # (ranks sharing a device: rehearsal of the launch only)
         feeder = StagedFeeder(trainer, min(args.steps, 16), B, S, 99 + rank, torch)
-        feeder.run(2)
+        # pinned-buffer creation leaves the process slow for some tens of steps (as communicator creation does): settle
+        # untimed; tools/staged_probe.py shows the staged and the resident loop level once settled
+        feeder.run(max(20, args.warmup))
         dts, _ = timed(feeder.run, args.steps)
         staged = {"ms_per_step": round(dts / args.steps * 1e3, 3),
                   "value": round(world * B * S * args.steps / dts, 1),
