@@ -162,6 +162,47 @@ def test_attention_fwd_bwd(B, S, NH, lens):
         assert (dqkv[kpad][:, H:] == 0).all()
 
 
+@pytest.mark.parametrize("ramp", [0.0, 0.02, 0.5])
+def test_attention_running_maximum(ramp):
+    """The forward rescales its accumulators only when a row maximum has grown by more than 2^8 and keeps a stale
+    reference otherwise. Keys whose scores grow along the sequence exercise both: ramp 0.5 moves the maximum by tens of
+    log2 units per 64-key tile (a rescale in every tile), 0.02 by a fraction of the threshold (stale reference with
+    probabilities above 1), 0 is the flat case. Forward, LSE and backward against fp32 torch."""
+    L = _lib.lib()
+    B, S, NH = 2, 512, 2
+    H = NH * 64
+    g = torch.Generator(device="cpu").manual_seed(77)
+    q = torch.randn(B * S, H, generator=g)
+    k = torch.randn(B * S, H, generator=g) * 0.3
+    v = torch.randn(B * S, H, generator=g)
+    # key j gets a component along the query's mean direction that grows with j: scores rise along the keys
+    qdir = torch.nn.functional.normalize(q.reshape(B, S, NH, 64).mean(1, keepdim=True), dim=-1)      # [B,1,NH,64]
+    pos = torch.arange(S, dtype=torch.float32).reshape(1, S, 1, 1)
+    k = (k.reshape(B, S, NH, 64) + ramp * pos * qdir).reshape(B * S, H)
+    q = (q.reshape(B, S, NH, 64) + 3.0 * qdir).reshape(B * S, H)                                       # queries lean that way
+    qkv = torch.cat([q, k, v], dim=1).to(torch.bfloat16).to(DEV).contiguous()
+    p, ctx, lse = attn_args(qkv, None, B, S, NH)
+    assert L.plb_launch_attn_fwd(C.byref(p), stream()) == 0
+    torch.cuda.synchronize()
+    rctx, rlse, grad = torch_attention(qkv, None, B, S, NH)
+    assert torch.isfinite(ctx.float()).all() and torch.isfinite(lse).all()
+    assert rel_l2(ctx.float(), rctx) < 6e-3
+    assert (-lse * p.scale - rlse).abs().max() < 2e-3 * max(1.0, float(rlse.abs().max()) / 10)
+    dctx = randbf(B * S, H, seed=11)
+    delta = torch.zeros((B, NH, S), dtype=torch.float32, device=DEV)
+    dqkv = torch.zeros((B * S, 3 * H), dtype=torch.bfloat16, device=DEV)
+    p.dctx, p.lddctx, p.delta, p.dqkv, p.lddqkv = dctx.data_ptr(), H, delta.data_ptr(), dqkv.data_ptr(), 3 * H
+    assert L.plb_launch_attn_bwd(C.byref(p), stream()) == 0
+    torch.cuda.synchronize()
+    ref = grad(dctx)
+    assert torch.isfinite(dqkv.float()).all()
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        # at ramp 0.5 the keys reach |k| = 250 along one direction and sum_k dS = 0 only in exact arithmetic: dq / dk are
+        # then differences of bf16-rounded terms 250x their size (ill-conditioned for any bf16 kernel); dv is not
+        if ramp < 0.1 or name == "dv":
+            assert rel_l2(dqkv[:, sl].float(), ref[:, sl]) < 2e-2, name
+
+
 @pytest.mark.parametrize("T,H", [(37, 128), (300, 768), (64, 1024)])
 def test_layernorm_fwd_bwd(T, H):
     L = _lib.lib()
