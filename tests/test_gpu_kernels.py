@@ -162,6 +162,38 @@ def test_attention_fwd_bwd(B, S, NH, lens):
         assert (dqkv[kpad][:, H:] == 0).all()
 
 
+def test_attention_race_screen():
+    """The attention kernels hand LDS stages between LDS-DMA (global_load_lds, waited by vmcnt) and fragment reads across
+    one barrier per tile: a mistake there shows as rare wrong tiles. Repeat launches must be bitwise identical."""
+    L = _lib.lib()
+    B, S, NH = 4, 512, 12
+    H = NH * 64
+    qkv = randbf(B * S, 3 * H, scale=1.0, seed=21)
+    lengths = torch.tensor([512, 449, 130, 65], dtype=torch.int32, device=DEV)
+    p, ctx, lse = attn_args(qkv, lengths, B, S, NH)
+    dctx = randbf(B * S, H, seed=22)
+    qmask = (torch.arange(S, device=DEV)[None, :] < lengths[:, None]).reshape(B * S, 1)
+    dctx = dctx * qmask.to(dctx.dtype)
+    delta = torch.zeros((B, NH, S), dtype=torch.float32, device=DEV)
+    dqkv = torch.zeros((B * S, 3 * H), dtype=torch.bfloat16, device=DEV)
+    p.dctx, p.lddctx, p.delta, p.dqkv, p.lddqkv = dctx.data_ptr(), H, delta.data_ptr(), dqkv.data_ptr(), 3 * H
+    first = None
+    for _ in range(40):
+        ctx.zero_(); dqkv.zero_()
+        assert L.plb_launch_attn_fwd(C.byref(p), stream()) == 0
+        assert L.plb_launch_attn_bwd(C.byref(p), stream()) == 0
+        torch.cuda.synchronize()
+        got = (ctx.clone(), lse.clone(), dqkv.clone())
+        if first is None:
+            first = got
+            rctx, _, grad = torch_attention(qkv, lengths, B, S, NH)
+            valid = qmask.reshape(-1)
+            assert rel_l2(ctx.float()[valid], rctx[valid]) < 6e-3
+            assert rel_l2(dqkv.float(), grad(dctx)) < 1.5e-2
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(got, first))
+
+
 @pytest.mark.parametrize("ramp", [0.0, 0.02, 0.5])
 def test_attention_running_maximum(ramp):
     """The forward rescales its accumulators only when a row maximum has grown by more than 2^8 and keeps a stale
