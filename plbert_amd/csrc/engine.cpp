@@ -289,9 +289,11 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   const int64_t Ls = tr ? L : 1;  // layers of activations kept
   e->Tcap = Tp;
   e->NMcap = Tp;
-  // LayerNorm-backward partial rows (tools/ln_bench.py --blocks): at H = 1024 512 workgroups are 22 % faster than 1024
-  // (12.1 vs 15.5 us standalone); at H = 768 they measure 2 % faster alone and 4 % slower inside the step
-  e->ln_blocks = H >= 1024 ? 512 : 1024;
+  // LayerNorm-backward partial rows (tools/ln_bench.py --blocks): 512 workgroups are 22 % faster than 1024 at H = 1024
+  // (12.1 vs 15.5 us standalone) and level at H = 768 (2 % faster alone, +-0.01 ms inside the step, where they also halve
+  // the side stream's pass over the partials); PLBERT_LN_BLOCKS overrides
+  e->ln_blocks = 512;
+  if (const char* v = getenv("PLBERT_LN_BLOCKS")) { const int n = atoi(v); if (n >= 64 && n <= 4096) e->ln_blocks = n; }
   e->emb_blocks = 2048;
   Carve cv;
   // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes
@@ -437,6 +439,7 @@ extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_av
   e->params = params; e->grads = grads; e->m = exp_avg; e->v = exp_avg_sq;
   e->ws = (char*)workspace;
   if (!e->side && grads) {  // created once, outside any launch sequence (a step may be graph-captured)
+    // (default priority: at the highest one the step measured the same, 10.20-10.22 ms either way)
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side = nullptr;
     if (e->side && (hipEventCreateWithFlags(&e->ev_fork, kStreamOrderEvent) != hipSuccess ||
                     hipEventCreateWithFlags(&e->ev_join, kStreamOrderEvent) != hipSuccess)) {

@@ -66,6 +66,9 @@ int launch_big(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {
 // those eight segments over all 64 banks (the swizzle is applied to the DMA's per-lane source chunk).
 DEVI int tn_g(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
+#ifndef TN_INTERLEAVE
+#define TN_INTERLEAVE 1
+#endif
 __global__ __launch_bounds__(512) void gemm_tn_big_kernel(PlbGemmTN p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * HT];  // [buf][A0,A1,B0,B1][2 images][64][64]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -180,6 +183,103 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(PlbGemmTN p) {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
   } while (0)
 
+#if TN_INTERLEAVE
+  // ---- interleaved K loop (the NT kernel's default form, see gemm_nt_pipeline.h): a phase is {BARRIER, 16 MFMAs}; the
+  // transposed fragment reads of the NEXT phase and the DMA issues are dealt one or two per MFMA into the shadows of those
+  // MFMAs; fragment buffers ping-pong (A0 -> ra2[0], A1 -> ra2[1]; B0 / B1 alternate between rb2[bb] and rb2[1-bb] from
+  // one K-tile to the next), so the loop is written for two K-tiles. One barrier per phase, no stagger.
+  //  ph1 (A0,B0): reads B1(t), issue A1(t+1)      ph2 (A0,B1): reads A1(t), issue A0(t+2)
+  //  ph3 (A1,B1): issue B0(t+2), B1(t+2); then the vmcnt wait        ph4 (A1,B0): reads A0(t+1), B0(t+1)
+  //  RAW: what ph4's shadows read (K-tile t+1's A0, B0) and what ph1 / ph2 of the next tile read (its B1, A1) was issued
+  //       before the three newest half-tiles that the wait leaves in flight; a BARRIER follows the wait.
+  //  WAR: a slot's previous occupant was read at the latest in the phase before the one whose shadows re-fill it, and
+  //       those reads retired at that phase's BARRIER (A1(t-1): ph2; A0(t), B0(t): ph4 of t-1; B1(t): ph1).
+  s16x4 ra2[2][4][4], rb2[2][2][4];  // [buffer][fragment][kk*2 + second]
+#define TR1(dst, addr, OFF) \
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=&v"(dst) : "v"(addr) : "memory")
+// read i (0..15) of an A half: fragment i>>2, piece i&3 (offsets 0, 512, 4096, 4608); i (0..7) of a B half
+#define RA1(ab, buf, h, i)                                                                                    \
+  do {                                                                                                        \
+    const unsigned ad_ = lds0 + 2u * (((buf) * 4 + (h)) * HT) + 2u * aoff[(i) >> 2];                          \
+    if (((i) & 3) == 0) TR1(ra2[ab][(i) >> 2][0], ad_, 0); else if (((i) & 3) == 1) TR1(ra2[ab][(i) >> 2][1], ad_, 512);      \
+    else if (((i) & 3) == 2) TR1(ra2[ab][(i) >> 2][2], ad_, 4096); else TR1(ra2[ab][(i) >> 2][3], ad_, 4608);                 \
+    PIN();                                                                                                    \
+  } while (0)
+#define RB1(bb, buf, h, i)                                                                                    \
+  do {                                                                                                        \
+    const unsigned ad_ = lds0 + 2u * (((buf) * 4 + 2 + (h)) * HT) + 2u * boff[(i) >> 2];                      \
+    if (((i) & 3) == 0) TR1(rb2[bb][(i) >> 2][0], ad_, 0); else if (((i) & 3) == 1) TR1(rb2[bb][(i) >> 2][1], ad_, 512);      \
+    else if (((i) & 3) == 2) TR1(rb2[bb][(i) >> 2][2], ad_, 4096); else TR1(rb2[bb][(i) >> 2][3], ad_, 4608);                 \
+    PIN();                                                                                                    \
+  } while (0)
+// MFMA j of a phase: j -> (kk, mi, ni)
+#define MF1(mh, nh, ab, bb, j)                                                                                \
+  do {                                                                                                        \
+    acc[mh][((j) >> 1) & 3][nh][(j) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                           \
+        FRAG(rb2[bb][(j) & 1], (j) >> 3), FRAG(ra2[ab][((j) >> 1) & 3], (j) >> 3), acc[mh][((j) >> 1) & 3][nh][(j) & 1], 0, 0, 0); \
+    PIN();                                                                                                    \
+  } while (0)
+#define PH1(mh, nh, ab, bb, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)              \
+  do {                                                                                                        \
+    BARRIER(); PIN();                                                                                         \
+    MF1(mh, nh, ab, bb, 0); s0; MF1(mh, nh, ab, bb, 1); s1; MF1(mh, nh, ab, bb, 2); s2; MF1(mh, nh, ab, bb, 3); s3;       \
+    MF1(mh, nh, ab, bb, 4); s4; MF1(mh, nh, ab, bb, 5); s5; MF1(mh, nh, ab, bb, 6); s6; MF1(mh, nh, ab, bb, 7); s7;       \
+    MF1(mh, nh, ab, bb, 8); s8; MF1(mh, nh, ab, bb, 9); s9; MF1(mh, nh, ab, bb, 10); s10; MF1(mh, nh, ab, bb, 11); s11;   \
+    MF1(mh, nh, ab, bb, 12); s12; MF1(mh, nh, ab, bb, 13); s13; MF1(mh, nh, ab, bb, 14); s14; MF1(mh, nh, ab, bb, 15); s15; \
+  } while (0)
+#define NOP_ (void)0
+#define TWO(x, y) do { x; y; } while (0)
+#define TN_STEP(bb)                                                                                           \
+  do {                                                                                                        \
+    const int b = t & 1;                                                                                      \
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;                                                              \
+    PH1(0, 0, 0, bb, RB1(1 - bb, b, 1, 0), RB1(1 - bb, b, 1, 1), RB1(1 - bb, b, 1, 2), RB1(1 - bb, b, 1, 3),   \
+        RB1(1 - bb, b, 1, 4), RB1(1 - bb, b, 1, 5), RB1(1 - bb, b, 1, 6), RB1(1 - bb, b, 1, 7),               \
+        TWO(if (n1) STAGE_A(b ^ 1, 1, t + 1), PIN()), NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);              \
+    PH1(0, 1, 0, 1 - bb, RA1(1, b, 1, 0), RA1(1, b, 1, 1), RA1(1, b, 1, 2), RA1(1, b, 1, 3), RA1(1, b, 1, 4), \
+        RA1(1, b, 1, 5), RA1(1, b, 1, 6), RA1(1, b, 1, 7), RA1(1, b, 1, 8), RA1(1, b, 1, 9), RA1(1, b, 1, 10), \
+        RA1(1, b, 1, 11), RA1(1, b, 1, 12), RA1(1, b, 1, 13), RA1(1, b, 1, 14),                              \
+        TWO(RA1(1, b, 1, 15), TWO(if (n2) STAGE_A(b, 0, t + 2), PIN())));                                    \
+    PH1(1, 1, 1, 1 - bb, NOP_, NOP_, TWO(if (n2) STAGE_B(b, 0, t + 2), PIN()), NOP_, NOP_, NOP_,              \
+        TWO(if (n2) STAGE_B(b, 1, t + 2), PIN()), NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);     \
+    LANDED(n2);                                                                                               \
+    PH1(1, 0, 1, bb, TWO(RA1(0, b ^ 1, 0, 0), RA1(0, b ^ 1, 0, 1)), TWO(RA1(0, b ^ 1, 0, 2), RA1(0, b ^ 1, 0, 3)), \
+        TWO(RA1(0, b ^ 1, 0, 4), RA1(0, b ^ 1, 0, 5)), TWO(RA1(0, b ^ 1, 0, 6), RA1(0, b ^ 1, 0, 7)),         \
+        TWO(RA1(0, b ^ 1, 0, 8), RA1(0, b ^ 1, 0, 9)), TWO(RA1(0, b ^ 1, 0, 10), RA1(0, b ^ 1, 0, 11)),       \
+        TWO(RA1(0, b ^ 1, 0, 12), RA1(0, b ^ 1, 0, 13)), TWO(RA1(0, b ^ 1, 0, 14), RA1(0, b ^ 1, 0, 15)),     \
+        RB1(1 - bb, b ^ 1, 0, 0), RB1(1 - bb, b ^ 1, 0, 1), RB1(1 - bb, b ^ 1, 0, 2), RB1(1 - bb, b ^ 1, 0, 3), \
+        RB1(1 - bb, b ^ 1, 0, 4), RB1(1 - bb, b ^ 1, 0, 5), RB1(1 - bb, b ^ 1, 0, 6), RB1(1 - bb, b ^ 1, 0, 7)); \
+  } while (0)
+  if (nk > 0) {
+    STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, 1, 0);
+    if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
+    LANDED(nk > 1);
+  }
+  BARRIER();
+  if (nk > 0) {
+    RA1(0, 0, 0, 0); RA1(0, 0, 0, 1); RA1(0, 0, 0, 2); RA1(0, 0, 0, 3); RA1(0, 0, 0, 4); RA1(0, 0, 0, 5); RA1(0, 0, 0, 6);
+    RA1(0, 0, 0, 7); RA1(0, 0, 0, 8); RA1(0, 0, 0, 9); RA1(0, 0, 0, 10); RA1(0, 0, 0, 11); RA1(0, 0, 0, 12);
+    RA1(0, 0, 0, 13); RA1(0, 0, 0, 14); RA1(0, 0, 0, 15);
+    RB1(0, 0, 0, 0); RB1(0, 0, 0, 1); RB1(0, 0, 0, 2); RB1(0, 0, 0, 3); RB1(0, 0, 0, 4); RB1(0, 0, 0, 5); RB1(0, 0, 0, 6);
+    RB1(0, 0, 0, 7);
+    int t = 0;
+    while (true) {
+      TN_STEP(0);
+      if (++t >= nk) break;
+      TN_STEP(1);
+      if (++t >= nk) break;
+    }
+    BARRIER();
+  }
+#undef TN_STEP
+#undef TWO
+#undef NOP_
+#undef PH1
+#undef MF1
+#undef RA1
+#undef RB1
+#undef TR1
+#else
   if (nk > 0) {
     STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, 1, 0);
     if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
@@ -205,6 +305,7 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(PlbGemmTN p) {
     MFMA_PART(1, 0, rb0);
   }
   if (wm == 0) BARRIER();
+#endif
 #undef STAGE_A
 #undef STAGE_B
 #undef TR4
