@@ -154,17 +154,7 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
 //  row image (row_off): LDS (row, chunk') <- source chunk chunk' ^ ((row >> 1) & 7)
 //  tr image  (tr_off):  LDS 16-byte unit u of 256-byte sub-tile t <- source (row 4(t>>1) + (u>>2), col 32(t&1) + 8(u&3))
 // Two stages: the DMA of tile t+1 is issued when tile t starts and waited for (vmcnt) at the barrier that ends it.
-// DMA in the scalar-base form (global_load_lds v_offset, s[base:base+1]): the per-lane 32-bit byte offsets are lane
-// constants for the whole kernel and the tile's base address advances on the scalar unit — through the builtin hipcc
-// keeps one running 64-bit pointer per instruction in VGPRs (20 registers and a 64-bit VALU add each per tile here).
-// M0 = LDS byte address of the 1-KiB (256-B for the dword form) destination; one wait state after writing M0.
-typedef __attribute__((address_space(3))) char lds_char;
-#define LDS_ADDR(ptr) ((uint32_t)(uintptr_t)(lds_char*)(ptr))
-#define DMA16(sbase, voff, ldsaddr) \
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory", "m0")
-#define DMA4(sbase, voff, ldsaddr) \
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory", "m0")
-#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// (DMA16 / DMA4 / LDS_ADDR / DMA_WAIT: common.h)
 // lane constants of the staging: image rows / source columns (elements) of this lane's two instructions
 struct StageLane { int rA, cA0, cA1, rT, cT; };
 DEVI StageLane stage_lane(int wave, int lane) {

@@ -83,6 +83,22 @@ DEVI float gelu_new_grad_f(float x) {
 DEVI s16x4 lds_read_tr16(const bf16_t* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
 }
+// the same from a byte address inside the workgroup's LDS (LDS_ADDR of the image + offsets)
+DEVI s16x4 lds_read_tr16_addr(uint32_t lds_byte_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)lds_byte_addr);
+}
+
+// DMA in the scalar-base form (global_load_lds v_offset, s[base:base+1]): the per-lane 32-bit byte offsets are lane
+// constants for the whole kernel and the tile's base address advances on the scalar unit — through the builtin hipcc
+// keeps one running 64-bit pointer per instruction in VGPRs (and a 64-bit VALU add each per tile).
+// M0 = LDS byte address of the 1-KiB (256-B for the dword form) destination; one wait state after writing M0.
+typedef __attribute__((address_space(3))) char lds_char;
+#define LDS_ADDR(ptr) ((uint32_t)(uintptr_t)(lds_char*)(ptr))
+#define DMA16(sbase, voff, ldsaddr) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory", "m0")
+#define DMA4(sbase, voff, ldsaddr) \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory", "m0")
+#define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 // XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
 // contiguous chunk of the logical tile order. Bijective for any nwg (cdna guide §5, T1).

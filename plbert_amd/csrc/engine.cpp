@@ -438,7 +438,7 @@ extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_av
   if ((uintptr_t)workspace & 255) return fail("plb_bind: workspace must be 256-byte aligned");
   e->params = params; e->grads = grads; e->m = exp_avg; e->v = exp_avg_sq;
   e->ws = (char*)workspace;
-  if (!e->side && grads) {  // created once, outside any launch sequence (a step may be graph-captured)
+  if (!e->side && grads && !getenv("PLBERT_NO_SIDE_STREAM")) {  // created once, outside any launch sequence (a step may be graph-captured)
     // (default priority: at the highest one the step measured the same, 10.20-10.22 ms either way)
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side = nullptr;
     if (e->side && (hipEventCreateWithFlags(&e->ev_fork, kStreamOrderEvent) != hipSuccess ||

@@ -69,7 +69,9 @@ DEVI int tn_g(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 #ifndef TN_INTERLEAVE
 #define TN_INTERLEAVE 1
 #endif
-__global__ __launch_bounds__(512) void gemm_tn_big_kernel(PlbGemmTN p) {
+// 224 VGPRs: two waves of this kernel then leave 64 registers of every SIMD (and 32 KiB of LDS) to the side stream's small
+// kernels, which run beside it on the same CUs (see the K loop)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224))) void gemm_tn_big_kernel(PlbGemmTN p) {
   __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 4 * HT];  // [buf][A0,A1,B0,B1][2 images][64][64]
   const int tid = threadIdx.x, lane = tid & 63;
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -185,83 +187,117 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(PlbGemmTN p) {
 
 #if TN_INTERLEAVE
   // ---- interleaved K loop (the NT kernel's default form, see gemm_nt_pipeline.h): a phase is {BARRIER, 16 MFMAs}; the
-  // transposed fragment reads of the NEXT phase and the DMA issues are dealt one or two per MFMA into the shadows of those
-  // MFMAs; fragment buffers ping-pong (A0 -> ra2[0], A1 -> ra2[1]; B0 / B1 alternate between rb2[bb] and rb2[1-bb] from
-  // one K-tile to the next), so the loop is written for two K-tiles. One barrier per phase, no stagger.
-  //  ph1 (A0,B0): reads B1(t), issue A1(t+1)      ph2 (A0,B1): reads A1(t), issue A0(t+2)
-  //  ph3 (A1,B1): issue B0(t+2), B1(t+2); then the vmcnt wait        ph4 (A1,B0): reads A0(t+1), B0(t+1)
+  // transposed fragment reads for the NEXT phase and the DMA issues are dealt into the shadows of those MFMAs. One barrier
+  // per phase, no stagger. The register budget decides the details: with 128 accumulators, ping-pong A buffers put the
+  // kernel at 254 VGPRs, i.e. two waves fill a SIMD's register file and the side stream's small kernels (16-64 VGPRs), which
+  // ran BESIDE the old 223-register kernel on the same CUs, were left with the 4-13 CUs it does not use: the whole step
+  // measured no faster although this kernel was 10 % faster alone. So A has ONE buffer that rolls: a phase issues its
+  // MFMAs fragment-major (mi = 0..3, each 2 k-steps x 2 B fragments), and once the four MFMAs of A fragment mi have
+  // issued, the reads of the NEXT A half's fragment mi go to the same registers; only fragment 3 cannot roll inside its
+  // phase and is read at the start of the next one, under that phase's first 12 MFMAs, with its own lgkmcnt wait.
+  // B keeps two buffers whose roles alternate from one K-tile to the next (loop written for two K-tiles).
+  //  ph1 (A0,B0): reads A0[3] (late), B1(t); issue A1(t+1)        ph2 (A0,B1): reads A1(t)[0..2]; issue A0(t+2)
+  //  ph3 (A1,B1): reads A1(t)[3] (late); issue B0(t+2), B1(t+2); then the vmcnt wait
+  //  ph4 (A1,B0): reads A0(t+1)[0..2], B0(t+1)
   //  RAW: what ph4's shadows read (K-tile t+1's A0, B0) and what ph1 / ph2 of the next tile read (its B1, A1) was issued
   //       before the three newest half-tiles that the wait leaves in flight; a BARRIER follows the wait.
   //  WAR: a slot's previous occupant was read at the latest in the phase before the one whose shadows re-fill it, and
-  //       those reads retired at that phase's BARRIER (A1(t-1): ph2; A0(t), B0(t): ph4 of t-1; B1(t): ph1).
-  s16x4 ra2[2][4][4], rb2[2][2][4];  // [buffer][fragment][kk*2 + second]
-#define TR1(dst, addr, OFF) \
-  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=&v"(dst) : "v"(addr) : "memory")
-// read i (0..15) of an A half: fragment i>>2, piece i&3 (offsets 0, 512, 4096, 4608); i (0..7) of a B half
-#define RA1(ab, buf, h, i)                                                                                    \
-  do {                                                                                                        \
-    const unsigned ad_ = lds0 + 2u * (((buf) * 4 + (h)) * HT) + 2u * aoff[(i) >> 2];                          \
-    if (((i) & 3) == 0) TR1(ra2[ab][(i) >> 2][0], ad_, 0); else if (((i) & 3) == 1) TR1(ra2[ab][(i) >> 2][1], ad_, 512);      \
-    else if (((i) & 3) == 2) TR1(ra2[ab][(i) >> 2][2], ad_, 4096); else TR1(ra2[ab][(i) >> 2][3], ad_, 4608);                 \
-    PIN();                                                                                                    \
+  //       those reads retired at that phase's BARRIER or at the explicit wait of a late fragment.
+  s16x4 ra1[4][4], rb2[2][2][4];  // [A fragment][kk*2 + second], [B buffer][fragment][kk*2 + second]
+// LDS addresses: one lane-constant base per (buffer, fragment) — the swizzle makes a fragment's offset non-linear in its
+// index — and everything else (half-tile, image piece) in the instruction's 16-bit offset field: a buffer spans 64 KiB.
+// The reads are the BUILTIN here (the staggered loop below needs them as asm because its DMAs are builtins: hipcc then
+// drains vmcnt before every LDS read that might alias one). With the DMAs written as asm nothing makes it do that, and
+// it tracks lgkmcnt for the reads itself — as asm, their outputs looked ready at once, and the 16-bit shuffles that
+// assemble a fragment from its two halves were hoisted above the arrival of the data (wrong results, not a crash).
+#define TR1(dst, addr, OFF) dst = lds_read_tr16_addr((addr) + (OFF))
+#define RD4(dst, ad_, o_)  /* the four pieces of one fragment */ \
+  do { TR1(dst[0], ad_, (o_)); TR1(dst[1], ad_, (o_) + 512); TR1(dst[2], ad_, (o_) + 4096); TR1(dst[3], ad_, (o_) + 4608); PIN(); } while (0)
+#define RA4(buf, h, mi) RD4(ra1[mi], abase[buf][mi], (h) * 16384)
+#define RB4(bb, buf, h, ni) RD4(rb2[bb][ni], bbase[buf][ni], (2 + (h)) * 16384)
+// DMA in the scalar-base form (common.h): lane-constant 32-bit offsets, the K-tile's base address on the scalar unit
+#define SA_(h, kt) ((const char*)p.A + ((size_t)(t_begin + (kt) * 64) * p.lda + bn * 256 + (h) * 128) * 2)
+#define SB_(h, kt) ((const char*)p.B + ((size_t)(t_begin + (kt) * 64) * p.ldb + bk * 256 + (h) * 128) * 2)
+#define STG_A(buf, h, kt)                                                                     \
+  do {                                                                                        \
+    const char* sb_ = SA_(h, kt);                                                             \
+    DMA16(sb_, vA0, ldsb + (((buf) * 4 + (h)) * HT + dst0) * 2);                              \
+    DMA16(sb_, vA1, ldsb + (((buf) * 4 + (h)) * HT + dst1) * 2);                              \
+    PIN();                                                                                    \
   } while (0)
-#define RB1(bb, buf, h, i)                                                                                    \
-  do {                                                                                                        \
-    const unsigned ad_ = lds0 + 2u * (((buf) * 4 + 2 + (h)) * HT) + 2u * boff[(i) >> 2];                      \
-    if (((i) & 3) == 0) TR1(rb2[bb][(i) >> 2][0], ad_, 0); else if (((i) & 3) == 1) TR1(rb2[bb][(i) >> 2][1], ad_, 512);      \
-    else if (((i) & 3) == 2) TR1(rb2[bb][(i) >> 2][2], ad_, 4096); else TR1(rb2[bb][(i) >> 2][3], ad_, 4608);                 \
-    PIN();                                                                                                    \
+#define STG_B(buf, h, kt)                                                                     \
+  do {                                                                                        \
+    const char* sb_ = SB_(h, kt);                                                             \
+    DMA16(sb_, vB0, ldsb + (((buf) * 4 + 2 + (h)) * HT + dst0) * 2);                          \
+    DMA16(sb_, vB1, ldsb + (((buf) * 4 + 2 + (h)) * HT + dst1) * 2);                          \
+    PIN();                                                                                    \
   } while (0)
-// MFMA j of a phase: j -> (kk, mi, ni)
-#define MF1(mh, nh, ab, bb, j)                                                                                \
-  do {                                                                                                        \
-    acc[mh][((j) >> 1) & 3][nh][(j) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                           \
-        FRAG(rb2[bb][(j) & 1], (j) >> 3), FRAG(ra2[ab][((j) >> 1) & 3], (j) >> 3), acc[mh][((j) >> 1) & 3][nh][(j) & 1], 0, 0, 0); \
-    PIN();                                                                                                    \
+  const uint32_t vA0 = (uint32_t)(r0 * p.lda + sc0) * 2, vA1 = (uint32_t)(r1 * p.lda + sc1) * 2;
+  const uint32_t vB0 = (uint32_t)(r0 * p.ldb + sc0) * 2, vB1 = (uint32_t)(r1 * p.ldb + sc1) * 2;
+  const uint32_t ldsb = LDS_ADDR(&smem[0]);
+  unsigned abase[2][4], bbase[2][2];
+#pragma unroll
+  for (int bf = 0; bf < 2; ++bf) {
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) abase[bf][mi] = lds0 + 65536u * bf + 2u * aoff[mi];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) bbase[bf][ni] = lds0 + 65536u * bf + 2u * boff[ni];
+  }
+// one piece (0..3 -> byte offsets 0, 512, 4096, 4608) of an A / B fragment
+#define PO_(pc) ((pc) == 0 ? 0 : (pc) == 1 ? 512 : (pc) == 2 ? 4096 : 4608)
+#define RA1(buf, h, mi, pc) do { TR1(ra1[mi][pc], abase[buf][mi], (h) * 16384 + PO_(pc)); PIN(); } while (0)
+#define RB1(bb, buf, h, ni, pc) do { TR1(rb2[bb][ni][pc], bbase[buf][ni], (2 + (h)) * 16384 + PO_(pc)); PIN(); } while (0)
+// MFMA j of a phase, fragment-major: mi = j >> 2, kk = (j >> 1) & 1, ni = j & 1 (each accumulator still sees kk = 0 first)
+#define MF1(mh, nh, bb, j)                                                                                      \
+  do {                                                                                                          \
+    acc[mh][(j) >> 2][nh][(j) & 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                   \
+        FRAG(rb2[bb][(j) & 1], ((j) >> 1) & 1), FRAG(ra1[(j) >> 2], ((j) >> 1) & 1), acc[mh][(j) >> 2][nh][(j) & 1], 0, 0, 0); \
+    PIN();                                                                                                      \
   } while (0)
-#define PH1(mh, nh, ab, bb, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)              \
-  do {                                                                                                        \
-    BARRIER(); PIN();                                                                                         \
-    MF1(mh, nh, ab, bb, 0); s0; MF1(mh, nh, ab, bb, 1); s1; MF1(mh, nh, ab, bb, 2); s2; MF1(mh, nh, ab, bb, 3); s3;       \
-    MF1(mh, nh, ab, bb, 4); s4; MF1(mh, nh, ab, bb, 5); s5; MF1(mh, nh, ab, bb, 6); s6; MF1(mh, nh, ab, bb, 7); s7;       \
-    MF1(mh, nh, ab, bb, 8); s8; MF1(mh, nh, ab, bb, 9); s9; MF1(mh, nh, ab, bb, 10); s10; MF1(mh, nh, ab, bb, 11); s11;   \
-    MF1(mh, nh, ab, bb, 12); s12; MF1(mh, nh, ab, bb, 13); s13; MF1(mh, nh, ab, bb, 14); s14; MF1(mh, nh, ab, bb, 15); s15; \
+#define PH1(mh, nh, bb, s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15)                    \
+  do {                                                                                                          \
+    BARRIER(); PIN();                                                                                           \
+    MF1(mh, nh, bb, 0); s0; MF1(mh, nh, bb, 1); s1; MF1(mh, nh, bb, 2); s2; MF1(mh, nh, bb, 3); s3;             \
+    MF1(mh, nh, bb, 4); s4; MF1(mh, nh, bb, 5); s5; MF1(mh, nh, bb, 6); s6; MF1(mh, nh, bb, 7); s7;             \
+    MF1(mh, nh, bb, 8); s8; MF1(mh, nh, bb, 9); s9; MF1(mh, nh, bb, 10); s10; MF1(mh, nh, bb, 11); s11;         \
+    MF1(mh, nh, bb, 12); s12; MF1(mh, nh, bb, 13); s13; MF1(mh, nh, bb, 14); s14; MF1(mh, nh, bb, 15); s15;     \
   } while (0)
 #define NOP_ (void)0
 #define TWO(x, y) do { x; y; } while (0)
-#define TN_STEP(bb)                                                                                           \
-  do {                                                                                                        \
-    const int b = t & 1;                                                                                      \
-    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;                                                              \
-    PH1(0, 0, 0, bb, RB1(1 - bb, b, 1, 0), RB1(1 - bb, b, 1, 1), RB1(1 - bb, b, 1, 2), RB1(1 - bb, b, 1, 3),   \
-        RB1(1 - bb, b, 1, 4), RB1(1 - bb, b, 1, 5), RB1(1 - bb, b, 1, 6), RB1(1 - bb, b, 1, 7),               \
-        TWO(if (n1) STAGE_A(b ^ 1, 1, t + 1), PIN()), NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);              \
-    PH1(0, 1, 0, 1 - bb, RA1(1, b, 1, 0), RA1(1, b, 1, 1), RA1(1, b, 1, 2), RA1(1, b, 1, 3), RA1(1, b, 1, 4), \
-        RA1(1, b, 1, 5), RA1(1, b, 1, 6), RA1(1, b, 1, 7), RA1(1, b, 1, 8), RA1(1, b, 1, 9), RA1(1, b, 1, 10), \
-        RA1(1, b, 1, 11), RA1(1, b, 1, 12), RA1(1, b, 1, 13), RA1(1, b, 1, 14),                              \
-        TWO(RA1(1, b, 1, 15), TWO(if (n2) STAGE_A(b, 0, t + 2), PIN())));                                    \
-    PH1(1, 1, 1, 1 - bb, NOP_, NOP_, TWO(if (n2) STAGE_B(b, 0, t + 2), PIN()), NOP_, NOP_, NOP_,              \
-        TWO(if (n2) STAGE_B(b, 1, t + 2), PIN()), NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_);     \
-    LANDED(n2);                                                                                               \
-    PH1(1, 0, 1, bb, TWO(RA1(0, b ^ 1, 0, 0), RA1(0, b ^ 1, 0, 1)), TWO(RA1(0, b ^ 1, 0, 2), RA1(0, b ^ 1, 0, 3)), \
-        TWO(RA1(0, b ^ 1, 0, 4), RA1(0, b ^ 1, 0, 5)), TWO(RA1(0, b ^ 1, 0, 6), RA1(0, b ^ 1, 0, 7)),         \
-        TWO(RA1(0, b ^ 1, 0, 8), RA1(0, b ^ 1, 0, 9)), TWO(RA1(0, b ^ 1, 0, 10), RA1(0, b ^ 1, 0, 11)),       \
-        TWO(RA1(0, b ^ 1, 0, 12), RA1(0, b ^ 1, 0, 13)), TWO(RA1(0, b ^ 1, 0, 14), RA1(0, b ^ 1, 0, 15)),     \
-        RB1(1 - bb, b ^ 1, 0, 0), RB1(1 - bb, b ^ 1, 0, 1), RB1(1 - bb, b ^ 1, 0, 2), RB1(1 - bb, b ^ 1, 0, 3), \
-        RB1(1 - bb, b ^ 1, 0, 4), RB1(1 - bb, b ^ 1, 0, 5), RB1(1 - bb, b ^ 1, 0, 6), RB1(1 - bb, b ^ 1, 0, 7)); \
+#define TN_STEP(bb)                                                                                             \
+  do {                                                                                                          \
+    constexpr int b = (bb); /* the loop alternates TN_STEP(0) / TN_STEP(1) from t = 0: buffer t & 1 is a literal */ \
+    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;                                                                \
+    /* ph1: A0 (fragment 3 arrives under the first 12 MFMAs), B0; B1(t) for ph2 */                              \
+    PH1(0, 0, bb, RA1(b, 0, 3, 0), RA1(b, 0, 3, 1), RA1(b, 0, 3, 2), RA1(b, 0, 3, 3),                           \
+        RB1(1 - bb, b, 1, 0, 0), RB1(1 - bb, b, 1, 0, 1), RB1(1 - bb, b, 1, 0, 2), RB1(1 - bb, b, 1, 0, 3),     \
+        RB1(1 - bb, b, 1, 1, 0), RB1(1 - bb, b, 1, 1, 1), RB1(1 - bb, b, 1, 1, 2), RB1(1 - bb, b, 1, 1, 3),     \
+        TWO(if (n1) STG_A(b ^ 1, 1, t + 1), NOP_), NOP_, NOP_, NOP_);                                           \
+    /* ph2: A0, B1; A1's fragments roll in behind the MFMAs that are done with A0's */                          \
+    PH1(0, 1, 1 - bb, NOP_, NOP_, NOP_, NOP_, RA1(b, 1, 0, 0), RA1(b, 1, 0, 1), RA1(b, 1, 0, 2), RA1(b, 1, 0, 3), \
+        RA1(b, 1, 1, 0), RA1(b, 1, 1, 1), RA1(b, 1, 1, 2), RA1(b, 1, 1, 3),                                     \
+        RA1(b, 1, 2, 0), RA1(b, 1, 2, 1), RA1(b, 1, 2, 2), TWO(RA1(b, 1, 2, 3), TWO(if (n2) STG_A(b, 0, t + 2), NOP_))); \
+    /* ph3: A1 (fragment 3 late), B1 */                                                                         \
+    PH1(1, 1, 1 - bb, RA1(b, 1, 3, 0), RA1(b, 1, 3, 1), RA1(b, 1, 3, 2), RA1(b, 1, 3, 3),                       \
+        TWO(if (n2) STG_B(b, 0, t + 2), NOP_), NOP_, NOP_, NOP_, TWO(if (n2) STG_B(b, 1, t + 2), NOP_), NOP_, NOP_, NOP_, \
+        NOP_, NOP_, NOP_, NOP_);                                                                                \
+    LANDED(n2);                                                                                                 \
+    /* ph4: A1, B0; the next K-tile's A0[0..2] roll in, its B0 goes to the buffer B1 has left */                \
+    PH1(1, 0, bb, RB1(1 - bb, b ^ 1, 0, 0, 0), RB1(1 - bb, b ^ 1, 0, 0, 1), RB1(1 - bb, b ^ 1, 0, 0, 2),        \
+        RB1(1 - bb, b ^ 1, 0, 0, 3),                                                                            \
+        TWO(RA1(b ^ 1, 0, 0, 0), RB1(1 - bb, b ^ 1, 0, 1, 0)), TWO(RA1(b ^ 1, 0, 0, 1), RB1(1 - bb, b ^ 1, 0, 1, 1)), \
+        TWO(RA1(b ^ 1, 0, 0, 2), RB1(1 - bb, b ^ 1, 0, 1, 2)), TWO(RA1(b ^ 1, 0, 0, 3), RB1(1 - bb, b ^ 1, 0, 1, 3)), \
+        RA1(b ^ 1, 0, 1, 0), RA1(b ^ 1, 0, 1, 1), RA1(b ^ 1, 0, 1, 2), RA1(b ^ 1, 0, 1, 3),                     \
+        RA1(b ^ 1, 0, 2, 0), RA1(b ^ 1, 0, 2, 1), RA1(b ^ 1, 0, 2, 2), RA1(b ^ 1, 0, 2, 3));                    \
   } while (0)
   if (nk > 0) {
-    STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, 1, 0);
-    if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
+    STG_A(0, 0, 0); STG_B(0, 0, 0); STG_B(0, 1, 0); STG_A(0, 1, 0);
+    if (nk > 1) { STG_A(1, 0, 1); STG_B(1, 0, 1); STG_B(1, 1, 1); }
     LANDED(nk > 1);
   }
   BARRIER();
   if (nk > 0) {
-    RA1(0, 0, 0, 0); RA1(0, 0, 0, 1); RA1(0, 0, 0, 2); RA1(0, 0, 0, 3); RA1(0, 0, 0, 4); RA1(0, 0, 0, 5); RA1(0, 0, 0, 6);
-    RA1(0, 0, 0, 7); RA1(0, 0, 0, 8); RA1(0, 0, 0, 9); RA1(0, 0, 0, 10); RA1(0, 0, 0, 11); RA1(0, 0, 0, 12);
-    RA1(0, 0, 0, 13); RA1(0, 0, 0, 14); RA1(0, 0, 0, 15);
-    RB1(0, 0, 0, 0); RB1(0, 0, 0, 1); RB1(0, 0, 0, 2); RB1(0, 0, 0, 3); RB1(0, 0, 0, 4); RB1(0, 0, 0, 5); RB1(0, 0, 0, 6);
-    RB1(0, 0, 0, 7);
+    RA4(0, 0, 0); RA4(0, 0, 1); RA4(0, 0, 2); RB4(0, 0, 0, 0); RB4(0, 0, 0, 1);
     int t = 0;
     while (true) {
       TN_STEP(0);
@@ -278,7 +314,15 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(PlbGemmTN p) {
 #undef MF1
 #undef RA1
 #undef RB1
+#undef PO_
+#undef RA4
+#undef RB4
+#undef RD4
 #undef TR1
+#undef STG_A
+#undef STG_B
+#undef SA_
+#undef SB_
 #else
   if (nk > 0) {
     STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, 1, 0);
@@ -319,17 +363,22 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(PlbGemmTN p) {
 
   // D[row = k][col = n] (B fragment first): lane owns dW[n = .. + li][k0 .. k0+3]
   float* out = p.slab + (size_t)split * p.N * p.K;
+  // the lane's coordinates are re-derived here (from mbcnt, behind an opaque copy): carried across the K loop they — or the
+  // thread id they come from — cost the registers that decide whether the kernel fits 224 VGPRs
+  int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));  // the lane id without v0
+  asm volatile("" : "+v"(lane_e));
+  const int li_e = lane_e & 15, fg_e = lane_e >> 4;
 #pragma unroll
   for (int mh = 0; mh < 2; ++mh)
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
-      const int n = bn * 256 + mh * 128 + wm * 64 + mi * 16 + li;
+      const int n = bn * 256 + mh * 128 + wm * 64 + mi * 16 + li_e;
       if (n >= p.N) continue;
 #pragma unroll
       for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
-          const int k0 = bk * 256 + nh * 128 + wn * 32 + ni * 16 + 4 * fg;
+          const int k0 = bk * 256 + nh * 128 + wn * 32 + ni * 16 + 4 * fg_e;
           const f32x4 v = acc[mh][mi][nh][ni];
           *(float4*)(out + (size_t)n * p.K + k0) = make_float4(v[0], v[1], v[2], v[3]);
         }
