@@ -82,25 +82,26 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   constexpr int EB = FP8 ? 1 : 2;
   const int ch0 = ((lane & 7) ^ ((lane >> 4) & 7)) * 16;
   const int ch1 = ((lane & 7) ^ ((4 + (lane >> 4)) & 7)) * 16;
-  const char* gA0 = (const char*)p.A + (size_t)(bm * TM + (2 * uw) * 8 + drow) * p.lda * EB + ch0;
-  const char* gA1 = (const char*)p.A + (size_t)(bm * TM + (2 * uw + 1) * 8 + drow) * p.lda * EB + ch1;
-  const char* gB0 = (const char*)p.B + (size_t)(bn * TN + (2 * uw) * 8 + drow) * p.ldb * EB + ch0;
-  const char* gB1 = (const char*)p.B + (size_t)(bn * TN + (2 * uw + 1) * 8 + drow) * p.ldb * EB + ch1;
+  // DMA in the scalar-base form (common.h): the lane offsets are constants of the kernel, the (half-tile, K-tile) base
+  // is formed on the scalar unit — through the builtin every instruction carried a 64-bit VGPR pointer and a VALU add
+  const uint32_t vA0 = (uint32_t)(((2 * uw) * 8 + drow) * p.lda * EB + ch0), vA1 = (uint32_t)(((2 * uw + 1) * 8 + drow) * p.lda * EB + ch1);
+  const uint32_t vB0 = (uint32_t)(((2 * uw) * 8 + drow) * p.ldb * EB + ch0), vB1 = (uint32_t)(((2 * uw + 1) * 8 + drow) * p.ldb * EB + ch1);
+  const char* const sA_ = (const char*)p.A + (size_t)(bm * TM) * p.lda * EB;
+  const char* const sB_ = (const char*)p.B + (size_t)(bn * TN) * p.ldb * EB;
   const size_t hA = (size_t)128 * p.lda * EB, hB = (size_t)128 * p.ldb * EB;
   const int dst0 = (2 * uw) * 8 * 64, dst1 = (2 * uw + 1) * 8 * 64;
+  const uint32_t ldsb_ = LDS_ADDR(&smem[0]);
 #define STAGE_A(slot, h, kt)                                                                                  \
   do {                                                                                                        \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (h) * hA + (size_t)(kt) * 128),                           \
-                                     (lptr_t)&smem[(slot) * HT + dst0], 16, 0, 0);                            \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (h) * hA + (size_t)(kt) * 128),                           \
-                                     (lptr_t)&smem[(slot) * HT + dst1], 16, 0, 0);                            \
+    const char* b_ = sA_ + (h) * hA + (size_t)(kt) * 128;                                                     \
+    DMA16(b_, vA0, ldsb_ + 2u * ((slot) * HT + dst0));                                                        \
+    DMA16(b_, vA1, ldsb_ + 2u * ((slot) * HT + dst1));                                                        \
   } while (0)
 #define STAGE_B(slot, h, kt)                                                                                  \
   do {                                                                                                        \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gB0 + (h) * hB + (size_t)(kt) * 128),                           \
-                                     (lptr_t)&smem[(slot) * HT + dst0], 16, 0, 0);                            \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gB1 + (h) * hB + (size_t)(kt) * 128),                           \
-                                     (lptr_t)&smem[(slot) * HT + dst1], 16, 0, 0);                            \
+    const char* b_ = sB_ + (h) * hB + (size_t)(kt) * 128;                                                     \
+    DMA16(b_, vB0, ldsb_ + 2u * ((slot) * HT + dst0));                                                        \
+    DMA16(b_, vB1, ldsb_ + 2u * ((slot) * HT + dst1));                                                        \
   } while (0)
 // half-tile i of a K-tile, in consumption order: A0, B0, B1, then A1 (256x256) or B2 (128x384)
 #define STAGE_I(i, slot, kt)                                              \
