@@ -92,12 +92,16 @@ DEVI s16x4 lds_read_tr16_addr(uint32_t lds_byte_addr) {
 // constants for the whole kernel and the tile's base address advances on the scalar unit — through the builtin hipcc
 // keeps one running 64-bit pointer per instruction in VGPRs (and a 64-bit VALU add each per tile).
 // M0 = LDS byte address of the 1-KiB (256-B for the dword form) destination; one wait state after writing M0.
+// M0 is written and read inside ONE statement and is not on the clobber list: hipcc reserves M0 and ignores such a
+// clobber (it only draws -Winline-asm). What makes this safe is that no compiler-generated instruction of these kernels
+// reads M0 — tests/test_cabi_and_host.py::test_m0_is_only_touched_by_the_dma_statements checks the disassembly of every
+// code object of the library for exactly that.
 typedef __attribute__((address_space(3))) char lds_char;
 #define LDS_ADDR(ptr) ((uint32_t)(uintptr_t)(lds_char*)(ptr))
 #define DMA16(sbase, voff, ldsaddr) \
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory", "m0")
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
 #define DMA4(sbase, voff, ldsaddr) \
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory", "m0")
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(sbase), "s"(ldsaddr) : "memory")
 #define DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 // XCD-aware block remap: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a

@@ -66,9 +66,6 @@ int launch_big(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {
 // those eight segments over all 64 banks (the swizzle is applied to the DMA's per-lane source chunk).
 DEVI int tn_g(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }
 
-#ifndef TN_INTERLEAVE
-#define TN_INTERLEAVE 1
-#endif
 // 224 VGPRs: two waves of this kernel then leave 64 registers of every SIMD (and 32 KiB of LDS) to the side stream's small
 // kernels, which run beside it on the same CUs (see the K loop)
 __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224))) void gemm_tn_big_kernel(PlbGemmTN p) {
@@ -96,27 +93,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224))) void gem
   const int r0 = (i0 & 7) * 8 + (lane >> 3), r1 = (i1 & 7) * 8 + (lane >> 3);
   const int sc0 = (((lane & 7) ^ (2 * tn_g(r0))) * 8) + (i0 >> 3) * 64;  // source column within the half
   const int sc1 = (((lane & 7) ^ (2 * tn_g(r1))) * 8) + (i1 >> 3) * 64;
-  const bf16_t* gA0 = p.A + (size_t)(t_begin + r0) * p.lda + bn * 256 + sc0;
-  const bf16_t* gA1 = p.A + (size_t)(t_begin + r1) * p.lda + bn * 256 + sc1;
-  const bf16_t* gB0 = p.B + (size_t)(t_begin + r0) * p.ldb + bk * 256 + sc0;
-  const bf16_t* gB1 = p.B + (size_t)(t_begin + r1) * p.ldb + bk * 256 + sc1;
-  const size_t tA = (size_t)64 * p.lda, tB = (size_t)64 * p.ldb;
   const int dst0 = (i0 >> 3) * 4096 + (i0 & 7) * 8 * 64, dst1 = (i1 >> 3) * 4096 + (i1 & 7) * 8 * 64;
-#define STAGE_A(buf, h, kt)                                                                                   \
-  do {                                                                                                        \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA0 + (h) * 128 + (size_t)(kt) * tA),                           \
-                                     (lptr_t)&smem[((buf) * 4 + (h)) * HT + dst0], 16, 0, 0);                 \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gA1 + (h) * 128 + (size_t)(kt) * tA),                           \
-                                     (lptr_t)&smem[((buf) * 4 + (h)) * HT + dst1], 16, 0, 0);                 \
-  } while (0)
-#define STAGE_B(buf, h, kt)                                                                                   \
-  do {                                                                                                        \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gB0 + (h) * 128 + (size_t)(kt) * tB),                           \
-                                     (lptr_t)&smem[((buf) * 4 + 2 + (h)) * HT + dst0], 16, 0, 0);             \
-    __builtin_amdgcn_global_load_lds((gptr_t)(gB1 + (h) * 128 + (size_t)(kt) * tB),                           \
-                                     (lptr_t)&smem[((buf) * 4 + 2 + (h)) * HT + dst1], 16, 0, 0);             \
-  } while (0)
-
   // ---- fragment reads (transposed): lane 4q+p of a 16-lane group supplies row q, columns 4p..4p+3;
   // k-step kk covers t rows kk*32 + 8*(lane>>4) + {0..3} (first read) and +4 (second read)
   const int fg = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
@@ -131,26 +108,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224))) void gem
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
     boff[ni] = (wn >> 1) * 4096 + rowbase + (((4 * (wn & 1) + 2 * ni + (p4 >> 1)) ^ gsw) << 3);
-  // The transposed reads are inline asm: through the builtin, hipcc cannot prove that a read does not
-  // alias an in-flight LDS-DMA and drains vmcnt to 0 before every phase's reads. The asm reads are
-  // invisible to its waitcnt pass; BARRIER() (lgkmcnt(0) + s_barrier, followed by a sched_barrier)
-  // retires them before any MFMA consumes a fragment, and fragments are only assembled after it.
   const unsigned lds0 = (unsigned)(size_t)&smem[0];
-  s16x4 ra[4][4], rb0[2][4], rb1[2][4];  // raw halves: [frag][kk*2 + second]
-#define TR4(dst, addr)                                                                                   \
-  asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:512\n\t"                  \
-               "ds_read_b64_tr_b16 %2, %4 offset:4096\n\tds_read_b64_tr_b16 %3, %4 offset:4608"           \
-               : "=&v"(dst[0]), "=&v"(dst[1]), "=&v"(dst[2]), "=&v"(dst[3]) : "v"(addr) : "memory")
-#define READ_A(buf, h)                                                                                   \
-  do {                                                                                                   \
-    const unsigned sb_ = lds0 + 2u * (((buf) * 4 + (h)) * HT);                                           \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) TR4(ra[mi], sb_ + 2u * aoff[mi]);                   \
-  } while (0)
-#define READ_B(dst, buf, h)                                                                              \
-  do {                                                                                                   \
-    const unsigned sb_ = lds0 + 2u * (((buf) * 4 + 2 + (h)) * HT);                                       \
-    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) TR4(dst[ni], sb_ + 2u * boff[ni]);                  \
-  } while (0)
 #define FRAG(r, kk) (bf16x8{r[2 * (kk)][0], r[2 * (kk)][1], r[2 * (kk)][2], r[2 * (kk)][3],              \
                             r[2 * (kk) + 1][0], r[2 * (kk) + 1][1], r[2 * (kk) + 1][2], r[2 * (kk) + 1][3]})
 
@@ -163,29 +121,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224))) void gem
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-#define MFMA_Q(mh, nh, rb)                                                                                     \
-  do {                                                                                                         \
-    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                           \
-      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                         \
-        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                       \
-          acc[mh][mi][nh][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FRAG(rb[ni], kk), FRAG(ra[mi], kk),    \
-                                                                        acc[mh][mi][nh][ni], 0, 0, 0);         \
-  } while (0)
-#define MFMA_PART(mh, nh, bf)            \
-  do {                                   \
-    BARRIER(); PIN();                    \
-    __builtin_amdgcn_s_setprio(1);       \
-    MFMA_Q(mh, nh, bf);                  \
-    __builtin_amdgcn_s_setprio(0);       \
-    PIN(); BARRIER(); PIN();             \
-  } while (0)
 #define LANDED(more)                                                      \
   do {                                                                    \
     if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
   } while (0)
 
-#if TN_INTERLEAVE
   // ---- interleaved K loop (the NT kernel's default form, see gemm_nt_pipeline.h): a phase is {BARRIER, 16 MFMAs}; the
   // transposed fragment reads for the NEXT phase and the DMA issues are dealt into the shadows of those MFMAs. One barrier
   // per phase, no stagger. The register budget decides the details: with 128 accumulators, ping-pong A buffers put the
@@ -206,10 +147,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224))) void gem
   s16x4 ra1[4][4], rb2[2][2][4];  // [A fragment][kk*2 + second], [B buffer][fragment][kk*2 + second]
 // LDS addresses: one lane-constant base per (buffer, fragment) — the swizzle makes a fragment's offset non-linear in its
 // index — and everything else (half-tile, image piece) in the instruction's 16-bit offset field: a buffer spans 64 KiB.
-// The reads are the BUILTIN here (the staggered loop below needs them as asm because its DMAs are builtins: hipcc then
-// drains vmcnt before every LDS read that might alias one). With the DMAs written as asm nothing makes it do that, and
+// The reads are the BUILTIN (beside builtin DMAs hipcc drains vmcnt before every LDS read that might alias one; with the
+// DMAs written as asm nothing makes it do that, and
 // it tracks lgkmcnt for the reads itself — as asm, their outputs looked ready at once, and the 16-bit shuffles that
 // assemble a fragment from its two halves were hoisted above the arrival of the data (wrong results, not a crash).
+// (The staggered two-barrier form of this loop, 6-9 % slower, was removed in round 3; it is in the history.)
 #define TR1(dst, addr, OFF) dst = lds_read_tr16_addr((addr) + (OFF))
 #define RD4(dst, ad_, o_)  /* the four pieces of one fragment */ \
   do { TR1(dst[0], ad_, (o_)); TR1(dst[1], ad_, (o_) + 512); TR1(dst[2], ad_, (o_) + 4096); TR1(dst[3], ad_, (o_) + 4608); PIN(); } while (0)
@@ -323,42 +265,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224))) void gem
 #undef STG_B
 #undef SA_
 #undef SB_
-#else
-  if (nk > 0) {
-    STAGE_A(0, 0, 0); STAGE_B(0, 0, 0); STAGE_B(0, 1, 0); STAGE_A(0, 1, 0);
-    if (nk > 1) { STAGE_A(1, 0, 1); STAGE_B(1, 0, 1); STAGE_B(1, 1, 1); }
-    LANDED(nk > 1);
-  }
-  BARRIER();
-  if (wm == 1) BARRIER();  // half-phase stagger, as in gemm_nt_big_kernel
-  for (int t = 0; t < nk; ++t) {
-    const int b = t & 1;
-    const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-    if (n1) STAGE_A(b ^ 1, 1, t + 1);
-    READ_B(rb0, b, 0);
-    READ_A(b, 0);
-    MFMA_PART(0, 0, rb0);
-    if (n2) STAGE_A(b, 0, t + 2);
-    READ_B(rb1, b, 1);
-    MFMA_PART(0, 1, rb1);
-    if (n2) STAGE_B(b, 0, t + 2);
-    READ_A(b, 1);
-    MFMA_PART(1, 1, rb1);
-    if (n2) STAGE_B(b, 1, t + 2);
-    LANDED(n2);
-    MFMA_PART(1, 0, rb0);
-  }
-  if (wm == 0) BARRIER();
-#endif
-#undef STAGE_A
-#undef STAGE_B
-#undef TR4
 #undef FRAG
-#undef READ_A
-#undef READ_B
-#undef MFMA_Q
-#undef MFMA_PART
-#undef PHASE
 #undef LANDED
 
   // D[row = k][col = n] (B fragment first): lane owns dW[n = .. + li][k0 .. k0+3]

@@ -19,11 +19,41 @@ def world_info(group=None):
     return 0, 1
 
 
-def shard_batch(batch, rank, world):
+def init_from_env():
+    """What ``Accelerator()`` does for the reference (train.py:218-221) when the process was started by ``torchrun`` /
+    ``accelerate launch``: join the process group named by RANK / WORLD_SIZE / MASTER_* and select this rank's GPU.
+    The group is the CONTROL plane only (gloo: barriers, the RCCL unique id, the fallback exchange); gradients travel
+    through the engine's own RCCL communicator. Returns (rank, world, device string or None when no launcher is
+    present). Idempotent."""
+    import os
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 and not (dist.is_available() and dist.is_initialized()):
+        return 0, 1, None
+    if not dist.is_initialized():
+        dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    device = None
+    if torch.cuda.is_available():
+        local = int(os.environ.get("LOCAL_RANK", rank)) % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(local)
+        device = f"cuda:{local}"
+    return rank, dist.get_world_size(), device
+
+
+def shard_batch(batch, rank, world, pad=False):
     """accelerate BatchSamplerShard(split_batches=True): contiguous equal slices of the collated batch.
-    ``batch`` = (labels [B,S], masked [B,S], lengths list, masked_indices list)."""
+    ``batch`` = (labels [B,S], masked [B,S], lengths list, masked_indices list).
+    ``pad``: a batch whose size is not a multiple of the world size (the last batch of a ``drop_last=False`` loader,
+    i.e. validation) is completed with its own first samples, as accelerate's ``even_batches=True`` does."""
     labels, masked, lengths, idx = batch
     B = len(lengths)
+    if B % world and pad:
+        extra = [i % B for i in range(world - B % world)]
+        take = list(range(B)) + extra
+        labels, masked = labels[take], masked[take]
+        lengths, idx = [lengths[i] for i in take], [idx[i] for i in take]
+        B = len(take)
     if B % world:
         raise ValueError(f"global batch {B} is not divisible by the world size {world}")
     per = B // world
@@ -32,16 +62,15 @@ def shard_batch(batch, rank, world):
 
 
 class GradReducer:
-    """Sum all-reduce of a flat gradient tensor on the CURRENT stream (default), or in contiguous pieces on a
-    side stream (``side_stream=True``) for callers that have later main-stream work to overlap.
+    """Sum all-reduce of a flat gradient tensor through ``torch.distributed`` — the FALLBACK exchange, used when the
+    engine's own RCCL communicator cannot be created (ranks sharing one device on the one-GPU test box: gloo) and by
+    the CPU world-2 tests. On the CURRENT stream by default, or in contiguous pieces on a side stream
+    (``side_stream=True``).
 
-    The training step uses the default. Its batched weight-gradient GEMMs make every large gradient final only
-    at the end of the backward, AdamW needs the reduced gradients right after, so there is
-    nothing for a side stream to overlap — and on MI355X the two cross-stream waits of a side-stream
-    collective cost 0.1–0.5 ms per step (tools/dist_overhead.py, world size 1), against 0 for the
-    in-stream call. Splitting the 23 MB into pieces ordered by completion was priced too: the gradients that
-    finish early are small (head 0.6 MB, embeddings 0.8 MB) and the flat order interleaves late and early
-    tensors, so it trades one collective for 7–8 latency-bound ones."""
+    The product exchange is NOT this class: ``plb_loss_fwd_bwd`` issues the all-reduce itself, piecewise, on the
+    engine's communication stream, each piece behind the weight-gradient GEMM that completed it
+    (``csrc/engine.cpp: reduce_piece``); ``plb_allreduce_grads`` joins it. This class reduces the whole
+    buffer after the backward because a host-side collective cannot be ordered between the launches of one C call."""
 
     def __init__(self, group=None, device=None, force=False, side_stream=False):
         self.group = group

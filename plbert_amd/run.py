@@ -24,10 +24,10 @@ import torch
 import torch.distributed as dist
 import yaml
 
-from .checkpoint import find_latest_checkpoint
+from .checkpoint import find_latest_checkpoint, optimizer_state_from_flat, optimizer_state_to_flat
 from .config import albert_config_from_yaml
 from .data import build_dataloader
-from .dist import shard_batch, world_info
+from .dist import init_from_env, shard_batch, world_info
 from .symbols import symbols
 
 MAX_EPOCHS = 10  # train.py:145
@@ -43,7 +43,19 @@ def parse_args(argv=None):
 def setup_config_and_directories(args, config_path):
     """Run folder decides: an existing folder that holds a copy of the config RESUMES with that copy; an existing folder
     without one is cleaned of ``step_*`` files and starts fresh; otherwise the folder is created (train.py:174-210).
-    Returns (config, log_dir, resuming)."""
+    Returns (config, log_dir, resuming). With several ranks only rank 0 touches the folder (the reference guards the
+    same block with ``accelerator.is_main_process``, train.py:181); the others read its decision after a barrier."""
+    rank, world = world_info()
+    if world > 1:
+        decided = [None]
+        if rank == 0:
+            decided[0] = _setup_run_dir(args, config_path)
+        dist.broadcast_object_list(decided, src=0)
+        return decided[0]
+    return _setup_run_dir(args, config_path)
+
+
+def _setup_run_dir(args, config_path):
     with open(config_path) as f:
         given = yaml.safe_load(f)
     log_dir = os.path.join(given["training_params"]["output_dir"], args["run_name"])
@@ -77,21 +89,21 @@ class _Log:
 
 
 def _state_for_file(trainer, step, epoch):
-    """``{'net','step','epoch','optimizer'}`` with the optimizer entry in torch.optim.AdamW's layout (indices in
-    state-dict order), as train.py:416-421 writes it."""
+    """``{'net','step','epoch','optimizer'}`` with the optimizer entry in torch.optim.AdamW's layout, as train.py:416-421
+    writes it: state indices count the reference's ``model.parameters()`` order (checkpoint.REFERENCE_PARAM_ORDER), so
+    the reference's ``optimizer.load_state_dict`` binds every moment to the tensor it belongs to."""
     eng = trainer.engine
-    names = list(eng.layout)
-    state = {}
     tok0 = eng.token_range[0]
-    for i, n in enumerate(names):
-        off, size, shp = eng.layout[n]
-        steps = trainer.step_count if off + size <= eng.trainable else (eng.token_head_steps if eng.num_tokens and off >= tok0 else 0)
-        if steps > 0:
-            state[i] = {"step": torch.tensor(float(steps)), "exp_avg": eng.exp_avg[off:off + size].view(shp).cpu().clone(),
-                        "exp_avg_sq": eng.exp_avg_sq[off:off + size].view(shp).cpu().clone()}
+
+    def steps_of(name, off, size):
+        if off + size <= eng.trainable:
+            return trainer.step_count
+        return eng.token_head_steps if eng.num_tokens and off >= tok0 else 0
+
+    state, n = optimizer_state_from_flat(eng.layout, eng.exp_avg, eng.exp_avg_sq, steps_of)
     group = {"lr": trainer.lr, "betas": tuple(trainer.betas), "eps": trainer.eps, "weight_decay": trainer.weight_decay,
              "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
-             "fused": None, "decoupled_weight_decay": True, "params": list(range(len(names)))}
+             "fused": None, "decoupled_weight_decay": True, "params": list(range(n))}
     return {"net": {k: v.cpu() for k, v in eng.state_dict().items()}, "step": step, "epoch": epoch,
             "optimizer": {"state": state, "param_groups": [group]}}
 
@@ -105,24 +117,22 @@ def save_checkpoint(trainer, current_step, log_dir, current_epoch, main=True):
 
 
 def load_checkpoint(trainer, path):
-    """Weights (``module.`` prefixes stripped, non-strict: train.py:98-100) and, when present, the AdamW state."""
+    """Weights (``module.`` prefixes stripped, non-strict: train.py:98-100) and, when present, the AdamW state — of a
+    file this driver wrote or of a reference ``step_N.pth`` (indices in ``model.parameters()`` order)."""
     ck = torch.load(path, map_location="cpu", weights_only=False)
     eng = trainer.engine
     eng.load_state_dict({k.replace("module.", ""): v for k, v in ck["net"].items()}, strict=False)
     opt = ck.get("optimizer")
     if opt and opt.get("state"):
-        names = list(eng.layout)
-        eng.exp_avg.zero_()
-        eng.exp_avg_sq.zero_()
-        main_steps, tok_steps = set(), set()
-        for i, st in opt["state"].items():
-            off, size, shp = eng.layout[names[int(i)]]
-            is_tok = bool(eng.num_tokens) and off >= eng.token_range[0]
-            if off + size > eng.trainable and not is_tok:
-                continue
-            eng.exp_avg[off:off + size].view(shp).copy_(st["exp_avg"])
-            eng.exp_avg_sq[off:off + size].view(shp).copy_(st["exp_avg_sq"])
-            (tok_steps if is_tok else main_steps).add(int(float(st["step"])))
+        tok0 = eng.token_range[0]
+
+        def is_tok(off):
+            return bool(eng.num_tokens) and off >= tok0
+
+        steps = optimizer_state_to_flat(opt["state"], eng.layout, eng.exp_avg, eng.exp_avg_sq,
+                                        lambda n, off, size: off + size <= eng.trainable or is_tok(off))  # not the pooler
+        main_steps = {v for n, v in steps.items() if not is_tok(eng.layout[n][0])}
+        tok_steps = {v for n, v in steps.items() if is_tok(eng.layout[n][0])}
         trainer.step_count = max(main_steps) if main_steps else 0
         eng.token_head_steps = max(tok_steps) if tok_steps else 0
     print(f"Checkpoint {path} loaded.", flush=True)
@@ -160,7 +170,8 @@ def _batches(loader, trainer, device_masking, word_separator):
                                 word_separator=word_separator)
         return
     for batch in loader:
-        lab, msk, lens, idx = shard_batch((np.asarray(batch[0]), np.asarray(batch[1]), batch[2], batch[3]), rank, world)
+        lab, msk, lens, idx = shard_batch((np.asarray(batch[0]), np.asarray(batch[1]), batch[2], batch[3]), rank, world,
+                                          pad=True)  # a ragged last (validation) batch: accelerate's even_batches
         yield trainer.stage_batch(lab, msk, lens, idx)
 
 
@@ -204,6 +215,10 @@ def train(args=None, dataset=None, device=None):
     """Drop-in for ``train.train(args)`` (train.py:133-172): ``args = {'config_path', 'run_name'}``. ``dataset``: rows of
     ``{'phonemes': [...]}``; None loads ``training_params.training_dataset`` with HF ``datasets`` as the reference does."""
     args = args or parse_args()
+    # under torchrun / accelerate launch: join the group and take this rank's GPU BEFORE anything touches a device or the
+    # run directory (the reference gets both from Accelerator(), train.py:218-221)
+    _, _, env_device = init_from_env()
+    device = device or env_device
     config, log_dir, resuming = setup_config_and_directories(args, args["config_path"])
     tp, dp = config["training_params"], dict(config["dataset_params"])
     main = world_info()[0] == 0

@@ -189,3 +189,76 @@ def test_bench_parent_spawns_ranks_without_touching_the_gpu(monkeypatch, capsys)
     assert capsys.readouterr().out.strip() == '{"metric": "phoneme-tokens/sec", "n_gpus": 4}'
     if "torch" in _sys.modules:
         assert _sys.modules["torch"].cuda.is_initialized() == torch_loaded_before
+
+
+def _disassemble_code_objects(tmp_path):
+    """Every gfx950 code object of the in-tree library, disassembled (llvm-objdump ships with ROCm; --offloading
+    writes the bundles next to its input, so it runs on a copy)."""
+    import glob
+    import shutil
+    import subprocess
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    lib = shutil.copy(os.path.join(ROOT, "plbert_amd", "libplbert_hip.so"), str(tmp_path))
+    subprocess.run([objdump, "--offloading", lib], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    cos = sorted(glob.glob(lib + ".*gfx950"))
+    assert cos, "no gfx950 code object extracted"
+    for co in cos:
+        yield co, subprocess.run([objdump, "-d", "--no-show-raw-insn", co], check=True, stdout=subprocess.PIPE,
+                                 text=True).stdout
+
+
+def test_m0_is_only_touched_by_the_dma_statements(tmp_path):
+    """The LDS-DMA statements (csrc/common.h: DMA16 / DMA4) write M0 and consume it in the same asm statement
+    (`s_mov_b32 m0, sN; s_nop 0; global_load_lds_*`) and do not declare the clobber (hipcc reserves M0 and ignores it).
+    That is safe only while the compiler itself never keeps a value in M0 across such a statement. Checked on the
+    disassembly, kernel by kernel: a kernel that contains the statement's signature must contain NO other use of M0 —
+    every write of M0 is the signature's, every LDS-DMA is the signature's, nothing reads M0. Kernels whose DMAs are
+    all the builtin's (csrc/gemm.hip) leave M0 to the compiler and are only required never to read it."""
+    n_asm = 0
+    for co, text in _disassemble_code_objects(tmp_path):
+        funcs, cur = {}, None
+        for ln in text.splitlines():
+            i = ln.split("//")[0].strip()
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", i)
+            if m:
+                cur = funcs.setdefault(m.group(1), [])
+            elif cur is not None and i and not i.endswith(":"):
+                cur.append(i)
+        for name, ins in funcs.items():
+            def dma(i):
+                return i.startswith("global_load_lds") or (i.startswith("buffer_load") and i.rstrip().endswith("lds"))
+            sig = [k for k in range(len(ins) - 2) if re.match(r"s_mov_b32 m0, s\d+$", ins[k]) and ins[k + 1] == "s_nop 0"
+                   and dma(ins[k + 2]) and " s[" in ins[k + 2]]  # scalar-base form: only the asm statements use it
+            for i in ins:
+                assert not re.match(r"(s_movrel|v_movrel|ds_gws|ds_ordered|s_sendmsg|v_interp)", i), (name, i)
+                if re.search(r"\bm0\b", i):  # M0 only ever as the destination of a scalar instruction
+                    assert re.match(r"s_\w+ m0, ", i) and not re.search(r"\bm0\b", i.split(",", 1)[1]), (name, i)
+            if not sig:
+                continue
+            n_asm += len(sig)
+            owned = set(sig) | {k + 2 for k in sig}
+            for k, i in enumerate(ins):
+                if dma(i) or re.search(r"\bm0\b", i):
+                    assert k in owned, (name, ins[max(0, k - 2):k + 3])
+    assert n_asm > 1000  # the pipeline GEMMs and the attention kernels really are LDS-DMA kernels
+
+
+def test_library_compiles_without_warnings(tmp_path):
+    """-Wall build of every source: a warning is either a real problem or noise that hides one."""
+    import subprocess
+    from plbert_amd import build as B
+
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not found")
+    procs = []
+    for src in B.SOURCES:
+        cmd = ["/opt/rocm/bin/hipcc", *B.FLAGS, "-x", "hip", "-c", os.path.join(B.CSRC, src), "-o",
+               str(tmp_path / (src + ".o"))]
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        assert p.returncode == 0, out[-2000:]
+        assert "warning" not in out, f"{src}:\n{out[:3000]}"

@@ -48,9 +48,16 @@ def test_run_directory_checkpoints_and_resume(tmp_path, device_masking):
     ck = torch.load(run_dir / "step_6.pth", map_location="cpu", weights_only=False)
     assert set(ck) == {"net", "step", "epoch", "optimizer"} and ck["step"] == 6
     assert "encoder.embeddings.word_embeddings.weight" in ck["net"] and "phoneme_predictor.weight" in ck["net"]
-    # torch's own AdamW accepts the optimizer entry (parameter order = state-dict order)
-    ps = [torch.nn.Parameter(v.clone().float()) for v in ck["net"].values()]
-    torch.optim.AdamW(ps, lr=1e-3).load_state_dict(ck["optimizer"])
+    # torch's own AdamW over parameters in the REFERENCE's model.parameters() order accepts the optimizer entry, and
+    # every moment has the shape of the parameter at its index (tests/test_checkpoint_order.py pins the order itself)
+    from plbert_amd.checkpoint import reference_param_names
+    order = reference_param_names({k: None for k in ck["net"]})
+    ps = [torch.nn.Parameter(ck["net"][n].clone().float()) for n in order]
+    topt = torch.optim.AdamW(ps, lr=1e-3)
+    topt.load_state_dict(ck["optimizer"])
+    for p_ in ps:
+        if p_ in topt.state:
+            assert topt.state[p_]["exp_avg"].shape == p_.shape
     recs = [json.loads(l) for l in (run_dir / "metrics.jsonl").read_text().splitlines()]
     assert "val_phoneme_loss" in recs[0] and recs[0]["step"] == 0                      # validation before the first step
     assert sum("val_phoneme_loss" in r for r in recs) == 3                             # step 0, 3, 6
@@ -71,3 +78,44 @@ def test_run_directory_checkpoints_and_resume(tmp_path, device_masking):
     os.remove(run_dir / "config.yml")
     _, _, resuming = prun.setup_config_and_directories(args, path)
     assert not resuming and not [f for f in os.listdir(run_dir) if f.startswith("step_")]
+
+
+def _launched_rank(rank, world, port, args, docs, out):
+    # what torchrun / accelerate launch export: train() must join the group and pick its GPU from these alone
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from plbert_amd import data as pdata_, run as prun_
+
+    torch.manual_seed(0)
+    pdata_.seed_reference_streams(1)
+    trainer, step, epoch = prun_.train(args, dataset=docs)
+    out[rank] = (step, trainer.world, trainer.comm, str(trainer.engine.device),
+                 trainer.engine.state_dict()["phoneme_predictor.weight"].cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_train_under_a_launcher_two_ranks(tmp_path):
+    """``train(args)`` started as two ranks (RANK / WORLD_SIZE / LOCAL_RANK in the environment, nothing else): each rank
+    joins the process group itself and takes GPU LOCAL_RANK (both map to the box's one GPU here), rank 0 alone creates
+    the run directory, writes metrics and checkpoints, the ragged last validation batch (7 documents, batch 4, two
+    ranks) is shared out instead of raising, and the replicas end bit-identical."""
+    import torch.multiprocessing as mp
+
+    path = _config(tmp_path, 4)
+    args = {"config_path": path, "run_name": "two"}
+    docs = (_docs() * 3)[:140]                            # 5 % validation split = 7 documents: batches of 4 and 3
+    assert len(docs) == 140
+    port = 29700 + (os.getpid() % 2000)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_launched_rank, args=(2, port, args, docs, out), nprocs=2, join=True)
+        res = dict(out)
+    assert res[0][0] == res[1][0] == 4 and res[0][1] == res[1][1] == 2
+    assert res[0][2] == res[1][2] == "torch"              # two ranks on one device: the gloo fallback, not RCCL
+    assert np.array_equal(res[0][4], res[1][4])
+    run_dir = tmp_path / "runs" / "two"
+    assert sorted(f for f in os.listdir(run_dir) if f.startswith("step_")) == ["step_3.pth"]
+    recs = [json.loads(l) for l in (run_dir / "metrics.jsonl").read_text().splitlines()]
+    assert [r["step"] for r in recs if "phoneme_loss" in r] == [1, 2, 3, 4]    # one writer
+    assert sum("val_phoneme_loss" in r for r in recs) == 2
