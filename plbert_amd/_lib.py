@@ -222,6 +222,10 @@ def lib():
     L.plb_launch_attn_fwd.argtypes = [C.POINTER(PlbAttn), vp]
     L.plb_launch_attn_bwd.restype = C.c_int
     L.plb_launch_attn_bwd.argtypes = [C.POINTER(PlbAttn), vp]
+    L.plb_launch_attn_bwd_fused.restype = C.c_int
+    L.plb_launch_attn_bwd_fused.argtypes = [C.POINTER(PlbAttn), vp]
+    L.plb_set_attn_bwd_fused.restype = None
+    L.plb_set_attn_bwd_fused.argtypes = [C.c_int]
     L.plb_launch_ln_fwd.restype = C.c_int
     L.plb_launch_ln_fwd.argtypes = [C.POINTER(PlbLayerNorm), vp]
     L.plb_launch_ln_bwd.restype = C.c_int

@@ -8,9 +8,14 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplbert_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_fp8.hip", "attn.hip", "rowops.hip", "mask.hip", "engine.cpp"]
-HEADERS = ["common.h", "plbert_kernels.h", "gemm_epilogue.h", "gemm_nt_pipeline.h", os.path.join("..", "..", "include", "plbert.h")]
+SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_fp8.hip", "attn.hip", "attn_bwd_fused.hip", "rowops.hip", "mask.hip", "engine.cpp"]
+HEADERS = ["common.h", "plbert_kernels.h", "gemm_epilogue.h", "gemm_nt_pipeline.h", "attn_common.h", os.path.join("..", "..", "include", "plbert.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# Per-source flags. attn_bwd_fused.hip is a one-wave-per-SIMD kernel with the whole 512-entry register file: by default
+# hipcc then selects the AGPR form for EVERY MFMA, so the S / dP tiles that the softmax arithmetic consumes land in
+# accumulator registers and cost a v_accvgpr_read each (+50 % VALU in a loop whose VALU and MFMA time are level). With
+# the VGPR form selected first, the register allocator places each MFMA result where its users want it.
+EXTRA_FLAGS = {"attn_bwd_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -38,7 +43,7 @@ def build(force=False, verbose=True):
     procs = []
     for src in SOURCES:
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, obj, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     objs = []
     for src, obj, p in procs:

@@ -49,7 +49,7 @@ std::vector<hipEvent_t> g_pool;
 const char* const kClassNames[PLB_K_NCLASS] = {
     "gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32", "gemm_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv",
     "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "reduce_slabs", "gather_scatter_rows", "cross_entropy",
-    "adamw", "cast_transpose", "token_ce", "gemm_nt_ce", "gemm_nt_small", "fp8_quantize"};
+    "adamw", "cast_transpose", "token_ce", "gemm_nt_ce", "gemm_nt_small", "fp8_quantize", "attn_bwd"};
 hipEvent_t prof_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;

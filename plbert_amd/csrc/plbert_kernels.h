@@ -12,7 +12,7 @@ extern "C" {
 enum PlbKernelClass {
   PLB_K_GEMM_NT = 0, PLB_K_GEMM_NT_GELU, PLB_K_GEMM_NT_GELUBWD, PLB_K_GEMM_NT_F32, PLB_K_GEMM_TN,
   PLB_K_ATTN_FWD, PLB_K_ATTN_BWD_DQ, PLB_K_ATTN_BWD_DKV, PLB_K_LN_FWD, PLB_K_LN_BWD, PLB_K_EMBED_FWD,
-  PLB_K_EMBED_BWD, PLB_K_COLSUM, PLB_K_REDUCE, PLB_K_ROWS, PLB_K_CE, PLB_K_ADAMW, PLB_K_CAST, PLB_K_TOKEN_CE, PLB_K_GEMM_NT_CE, PLB_K_GEMM_NT_SMALL, PLB_K_FP8, PLB_K_NCLASS
+  PLB_K_EMBED_BWD, PLB_K_COLSUM, PLB_K_REDUCE, PLB_K_ROWS, PLB_K_CE, PLB_K_ADAMW, PLB_K_CAST, PLB_K_TOKEN_CE, PLB_K_GEMM_NT_CE, PLB_K_GEMM_NT_SMALL, PLB_K_FP8, PLB_K_ATTN_BWD, PLB_K_NCLASS
 };
 int plb_prof_begin(int cls, hipStream_t s, double flops, double bytes);
 void plb_prof_end(int tok, hipStream_t s);
@@ -144,7 +144,11 @@ typedef struct {
   int colpart_accumulate;       // add to colpart instead of overwriting (sum over the applications of the shared layer)
 } PlbAttn;
 int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream);
-int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream);  // dq (+delta) then dk,dv
+// Default: the two-kernel form, dq (+delta) then dk,dv. plb_set_attn_bwd_fused(1) / PLBERT_ATTN_BWD=fused: ONE kernel for
+// S <= 512 (attn_bwd_fused.hip: 5 products, dQ complete inside the workgroup; delta is not written)
+int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream);
+int plb_launch_attn_bwd_fused(const PlbAttn* p, hipStream_t stream);
+void plb_set_attn_bwd_fused(int on);
 
 // Loss rows: row r of the gathered matrix is token rows[r]
 int plb_launch_gather_rows(const bf16_t* src, int lds_, const int32_t* rows, int n, int npad, int H, bf16_t* dst,

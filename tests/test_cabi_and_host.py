@@ -255,7 +255,7 @@ def test_library_compiles_without_warnings(tmp_path):
         pytest.skip("hipcc not found")
     procs = []
     for src in B.SOURCES:
-        cmd = ["/opt/rocm/bin/hipcc", *B.FLAGS, "-x", "hip", "-c", os.path.join(B.CSRC, src), "-o",
+        cmd = ["/opt/rocm/bin/hipcc", *B.FLAGS, *B.EXTRA_FLAGS.get(src, []), "-x", "hip", "-c", os.path.join(B.CSRC, src), "-o",
                str(tmp_path / (src + ".o"))]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for src, p in procs:

@@ -125,9 +125,20 @@ def test_gemm_tn_big(Mtot, N, K, splits, rps):
     assert rel_l2(out, ref) < 1e-5
 
 
+@pytest.fixture
+def bwd_form(request):
+    """Selects the attention backward: 0 = dq + dkv kernels (the default), 1 = the single-kernel form (S <= 512)."""
+    L = _lib.lib()
+    L.plb_set_attn_bwd_fused(int(request.param))
+    yield int(request.param)
+    L.plb_set_attn_bwd_fused(0)
+
+
+@pytest.mark.parametrize("bwd_form", [1, 0], indirect=True)
 @pytest.mark.parametrize("B,S,NH,lens", [(3, 40, 2, [40, 33, 7]), (2, 512, 3, [512, 300]), (2, 130, 2, None),
-                                         (1, 64, 1, [1])])
-def test_attention_fwd_bwd(B, S, NH, lens):
+                                         (1, 64, 1, [1]), (3, 512, 2, [129, 256, 511]), (2, 257, 1, [257, 31]),
+                                         (1, 600, 1, [600])])
+def test_attention_fwd_bwd(B, S, NH, lens, bwd_form):
     L = _lib.lib()
     H = NH * 64
     qkv = randbf(B * S, 3 * H, scale=1.0, seed=9)
@@ -157,12 +168,43 @@ def test_attention_fwd_bwd(B, S, NH, lens):
             assert float(dqkv[:, sl].float().abs().max()) < 1e-5, name
         else:
             assert rel_l2(dqkv[:, sl].float(), ref[:, sl]) < 1.5e-2, name
-    if lens:  # padded keys get exactly zero dK, dV
+    if lens:  # padded keys get exactly zero dK, dV — and padded queries exactly zero dQ
         kpad = ~(torch.arange(S, device=DEV)[None, :] < lengths[:, None]).reshape(B * S)
-        assert (dqkv[kpad][:, H:] == 0).all()
+        assert (dqkv[kpad] == 0).all()
 
 
-def test_attention_race_screen():
+@pytest.mark.parametrize("bwd_form", [1, 0], indirect=True)
+@pytest.mark.parametrize("B,S,NH,lens", [(2, 512, 2, [512, 300]), (2, 130, 3, [130, 77]), (1, 64, 1, None)])
+def test_attention_bwd_bias_gradient_partials(B, S, NH, lens, bwd_form):
+    """colpart: the rows the backward leaves for the Q/K/V bias gradient sum to the column sums of the dqkv it stored,
+    for the overwrite call (last layer) and the accumulating calls (the other applications of the shared layer)."""
+    L = _lib.lib()
+    H = NH * 64
+    QT = (S + 127) // 128
+    qkv = randbf(B * S, 3 * H, scale=1.0, seed=19)
+    lengths = torch.tensor(lens, dtype=torch.int32, device=DEV) if lens else None
+    p, ctx, lse = attn_args(qkv, lengths, B, S, NH)
+    assert L.plb_launch_attn_fwd(C.byref(p), stream()) == 0
+    colp = torch.full((B * QT * 4, 3 * H), 3.0, dtype=torch.float32, device=DEV)
+    delta = torch.zeros((B, NH, S), dtype=torch.float32, device=DEV)
+    total = torch.zeros(3 * H, dtype=torch.float64, device=DEV)
+    for call in range(3):
+        dctx = randbf(B * S, H, seed=40 + call)
+        if lens:
+            qmask = (torch.arange(S, device=DEV)[None, :] < lengths[:, None]).reshape(B * S, 1)
+            dctx = dctx * qmask.to(dctx.dtype)
+        dqkv = torch.zeros((B * S, 3 * H), dtype=torch.bfloat16, device=DEV)
+        p.dctx, p.lddctx, p.delta, p.dqkv, p.lddqkv = dctx.data_ptr(), H, delta.data_ptr(), dqkv.data_ptr(), 3 * H
+        p.colpart, p.colpart_accumulate = colp.data_ptr(), int(call > 0)
+        assert L.plb_launch_attn_bwd(C.byref(p), stream()) == 0
+        torch.cuda.synchronize()
+        total += dqkv.double().sum(0)
+        got = colp.double().sum(0)
+        assert torch.allclose(got, total, rtol=1e-5, atol=1e-3 * float(total.abs().max())), call
+
+
+@pytest.mark.parametrize("bwd_form", [0, 1], indirect=True)
+def test_attention_race_screen(bwd_form):
     """The attention kernels hand LDS stages between LDS-DMA (global_load_lds, waited by vmcnt) and fragment reads across
     one barrier per tile: a mistake there shows as rare wrong tiles. Repeat launches must be bitwise identical."""
     L = _lib.lib()

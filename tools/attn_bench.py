@@ -54,7 +54,7 @@ def bench(L, B, S, NH, iters=30):
     names = [L.plb_profile_class_name(i).decode() for i in range(n)]
     split = {names[i]: ms[i] / cnt[i] * 1e3 for i in range(n) if cnt[i]}
     out.append(split.get("attn_bwd_dq", 0.0))
-    out.append(split.get("attn_bwd_dkv", 0.0))
+    out.append(split.get("attn_bwd_dkv", 0.0) + split.get("attn_bwd", 0.0))   # single-kernel form: all under "attn_bwd"
     return out
 
 
@@ -62,13 +62,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--libs", default="")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--fused", action="store_true", help="time the single-kernel backward instead of dq + dkv")
+    ap.add_argument("--shapes", default="32x512x12", help="comma list of BxSxNH")
     args = ap.parse_args()
     libs = [("main", _lib.lib())]
+    _lib.lib().plb_set_attn_bwd_fused(1 if args.fused else 0)
     for path in [q for q in args.libs.split(",") if q]:
         libs.append((os.path.basename(path), C.CDLL(os.path.abspath(path), mode=C.RTLD_LOCAL)))
+        libs[-1][1].plb_set_attn_bwd_fused(1 if args.fused else 0)
     res = {}
     for rep in range(args.reps):
-        for (B, S, NH) in ((32, 512, 12),):
+        for (B, S, NH) in [tuple(int(x) for x in sh.split("x")) for sh in args.shapes.split(",")]:
             for name, L in libs:
                 f, b, dq, dkv = bench(L, B, S, NH)
                 res.setdefault((name, B, S, NH), []).append((f, b, dq, dkv))
