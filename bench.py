@@ -35,7 +35,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
-FLOP_PER_TOKEN_STEP = 454_440_960  # 3 x 151,480,320 forward, config A
+MFMA_FP8_PEAK_TFLOPS = 5000.0   # dense fp8 (block-scaled K = 128 form), same guide
+FLOP_PER_TOKEN_STEP = 454_440_960  # 3 x 151,480,320 forward, config A (checked against the formula below)
+
+
+def flop_per_token_step(cfg, seq, num_phonemes, num_tokens=0):
+    """Algorithmic FLOPs per token of one training step = 3 x forward: per shared-layer application
+    QKV 6H^2 + dense 2H^2 + FFN 4HI + attention 4SH (scores + context over S keys), plus the map-in 2EH and the phoneme
+    head 2H*NP counted over every token as the survey does; a token head adds its three GEMMs."""
+    H, I, E, L = cfg.hidden_size, cfg.intermediate_size, cfg.embedding_size, cfg.num_hidden_layers
+    fwd = L * (8 * H * H + 4 * H * I + 4 * seq * H) + 2 * E * H + 2 * H * num_phonemes
+    return 3 * fwd + 3 * 2 * H * num_tokens
 
 
 def parse():
@@ -66,6 +76,8 @@ def parse():
                     help="piecewise all-reduce inside the backward (on) or one collective after it (off); auto times "
                          "both during warm-up and keeps the faster")
     ap.add_argument("--no-staged", action="store_true", help="skip the per-step-staging re-run")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short child runs of BASELINE.json configs[3] (--model large) and configs[4] (--dtype fp8)")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8 = BASELINE configs[4], a separately reported workload: the QKV / FFN GEMMs (forward and FFN "
                          "dX) on e4m3 / e5m2 operands through the block-scaled MFMA, everything else as in bf16")
@@ -162,7 +174,7 @@ def pmc_traffic(cls):
         try:
             cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--",
                    sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                   "--no-roofline", "--no-traffic", "--no-staged"]
+                   "--no-roofline", "--no-traffic", "--no-staged", "--no-secondary"]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -183,6 +195,38 @@ def pmc_traffic(cls):
             shutil.rmtree(d, ignore_errors=True)
     fetch, write = tot["FETCH_SIZE"] * 1024 * 2, tot["WRITE_SIZE"] * 1024
     return {"bytes": round(fetch + write), "fetch": round(fetch), "write": round(write), "launches_sampled": launches}
+
+
+def secondary_lines():
+    """BASELINE.json configs[3] and configs[4] beside the headline: short runs of this script as fresh child processes,
+    one after the other (a child is a new process with its own HIP context; nothing is exec'ed over this one). Each
+    entry carries what its child's JSON line says; the parity tolerance of the fp8 path is part of the entry because it
+    is NOT the north-star's 1e-3 (tests/test_gpu_fp8.py: no fp8 reference exists, parity is against this build's bf16
+    path)."""
+    import subprocess
+
+    out = {}
+    for key, extra in (("large", ["--model", "large"]), ("fp8", ["--dtype", "fp8"])):
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "4", "--no-cpu-baseline",
+               "--no-traffic", "--no-staged", "--no-secondary", *extra]
+        try:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240, text=True)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[key] = {"error": f"child run failed (rc {r.returncode})"}
+                continue
+            j = json.loads(line[-1])
+            rl = j.get("roofline") or {}
+            out[key] = {"ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"],
+                        "step_mfma_frac_wall": j["step_mfma_frac_wall"], "step_loss": j["step_loss"],
+                        "workload": j["config"]["workload"], "dominant_kernel": rl.get("kernel"),
+                        "dominant_frac": rl.get("frac"), "dominant_peak_TFLOPs": rl.get("peak")}
+            if key == "fp8":
+                out[key]["parity"] = ("loss within 2e-2 relative of this build's bf16 path and of the reference; per-tensor "
+                                      "gradient relative L2 <= 0.25 (tests/test_gpu_fp8.py) - NOT the 1e-3 of the bf16 path")
+        except Exception as ex:  # the headline line must still be printed
+            out[key] = {"error": repr(ex)}
+    return out
 
 
 class StagedFeeder:
@@ -300,16 +344,19 @@ def main():
     if args.model == "large":
         cfg = plbert_amd.AlbertConfig(vocab_size=len(plbert_amd.symbols), hidden_size=1024, num_attention_heads=16,
                                       intermediate_size=4096, max_position_embeddings=512, num_hidden_layers=24)
-        flop_per_token = 1_964_875_776
         if args.batch == 32:
             args.batch = 16
         model_desc = "hidden 1024 / 24 shared layers / FFN 4096 / 16 heads"
     else:
         cfg = plbert_amd.AlbertConfig(vocab_size=len(plbert_amd.symbols), hidden_size=768, num_attention_heads=12,
                                       intermediate_size=2048, max_position_embeddings=512, num_hidden_layers=12)
-        flop_per_token = FLOP_PER_TOKEN_STEP
         model_desc = "hidden 768 / 12 shared layers / FFN 2048 / 12 heads"
     B, S = args.batch, args.seq
+    # from the shapes, so that --seq / --model / --num-tokens keep the roofline fractions right (the attention term grows
+    # with S); equals the survey's constants at its two configurations
+    flop_per_token = flop_per_token_step(cfg, S, len(plbert_amd.symbols), args.num_tokens)
+    if args.model == "base" and S == 512 and not args.num_tokens:
+        assert flop_per_token == FLOP_PER_TOKEN_STEP
     def make_trainer(mode, group=None):
         return PLBertTrainer(cfg, num_phonemes=len(plbert_amd.symbols), max_batch=B, max_seq=S, lr=7e-5,
                              device=f"cuda:{dev_index}", seed=0, force_collectives=args.force_dist,
@@ -331,6 +378,10 @@ def main():
             comm_note = (f"plb_comm_init failed ({failure or 'on another rank'}); gradients exchanged by "
                          "torch.distributed (nccl = RCCL) instead")
             print("bench.py: " + comm_note, file=sys.stderr, flush=True)
+            if args.comm == "rccl":
+                # asked for explicitly: a run that is meant to prove the engine's own exchange must not report a number
+                # measured on the fallback
+                raise SystemExit("bench.py: --comm rccl was requested and the engine's communicator did not come up")
             if trainer is not None:
                 trainer.engine.comm_destroy()
                 del trainer
@@ -344,7 +395,6 @@ def main():
     token_ids = None
     if args.num_tokens:
         token_ids = np.random.RandomState(4321 + rank).randint(0, args.num_tokens, size=(B, S)).astype(np.int64)
-        flop_per_token += 3 * 2 * cfg.hidden_size * args.num_tokens  # token head fwd + dgrad + wgrad
         model_desc += f" + token head {args.num_tokens}"
     batch = trainer.stage_batch(labels, masked, lengths, idx, token_ids=token_ids)  # resident in HBM before timing
 
@@ -421,6 +471,9 @@ def main():
     run_steps(args.warmup)
     dt, loss = timed(run_steps, args.steps)
     loss_val = float(loss.item())
+    if trainer.comm == "rccl":  # which form of the exchange the timed steps really ran
+        n_coll, n_floats = eng.comm_pieces()
+        comm_info.update(pieces_per_step=n_coll, floats_per_step=n_floats)
 
     # ---- the same K steps with a fresh batch staged every step (H2D inside the timed region) -------------------
     staged = None
@@ -487,8 +540,9 @@ def main():
             per_launch_flop = dom["flops"] / dom["launches"]
             avg_ms = dom["ms"] / dom["launches"]
             ach = per_launch_flop / (avg_ms * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            peak = MFMA_FP8_PEAK_TFLOPS if name.endswith("_fp8") else MFMA_BF16_PEAK_TFLOPS
+            roofline = {"bound": "mfma", "kernel": name, "achieved": round(ach, 1), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                         "avg_launch_us": round(avg_ms * 1e3, 2), "launches_per_step": dom["launches"] // args.steps,
                         "share_of_kernel_time": round(dom["ms"] / total_ms, 3),
                         "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in
@@ -519,6 +573,10 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.num_tokens:
         cpu = cpu_baseline(args.cpu_seconds)
+    secondary = None
+    if (rank == 0 and world == 1 and not dist.is_initialized() and not args.no_secondary and args.model == "base"
+            and args.dtype == "bf16" and not args.num_tokens and args.batch == 32 and args.seq == 512):
+        secondary = secondary_lines()
 
     if rank == 0:
         tokens = world * B * S * args.steps
@@ -535,6 +593,10 @@ def main():
             "ranks_seen": ranks_seen, "comm": comm_info, "staged": staged,
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if secondary is not None:
+            out["secondary"] = secondary
+        if args.dtype == "fp8":
+            out["config"]["parity"] = "fp8 path: loss within 2e-2 relative of the bf16 path (tests/test_gpu_fp8.py), not 1e-3"
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -177,6 +177,11 @@ int plb_comm_unique_id(uint8_t id[PLB_COMM_ID_BYTES]);
 int plb_comm_init(PlbEngine* e, const uint8_t id[PLB_COMM_ID_BYTES], int32_t rank, int32_t world);
 int plb_comm_destroy(PlbEngine* e);
 int plb_comm_info(const PlbEngine* e, int32_t* rank, int32_t* world, int32_t* rccl_version);
+/* What the last training step exchanged: the number of collectives it issued (8 pieces for the reference's phoneme-only
+ * step with overlap on, 1 with overlap off; one more after a dual-head step) and the floats they covered. The reference
+ * has no counterpart (DDP's bucket count is internal to torch, train.py:218-221); a caller logs it to see which form of
+ * the exchange actually ran. */
+int plb_comm_pieces(const PlbEngine* e, int32_t* collectives, int64_t* floats);
 /* DDP's start-up broadcast of rank `root`'s parameters; refreshes the bf16 copies. */
 int plb_broadcast_params(PlbEngine* e, int32_t root, void* stream);
 /* overlap = 1 (default): plb_loss_fwd_bwd[_dual] itself issues the gradient all-reduce, in contiguous pieces of the

@@ -54,7 +54,7 @@ PUBLIC_SYMBOLS = [
     "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
     "plb_sync_weights", "plb_forward", "plb_pooler", "plb_loss_fwd_bwd", "plb_loss_fwd", "plb_loss_fwd_bwd_dual", "plb_adamw_step",
     "plb_set_fp8", "plb_fp8_state", "plb_token_head_steps", "plb_set_token_head_steps", "plb_comm_unique_id", "plb_comm_init", "plb_comm_destroy",
-    "plb_comm_info", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
+    "plb_comm_info", "plb_comm_pieces", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
     "plb_mask_batch", "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
 ]
 
@@ -183,6 +183,8 @@ def lib():
     L.plb_comm_destroy.argtypes = [vp]
     L.plb_comm_info.restype = C.c_int
     L.plb_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.plb_comm_pieces.restype = C.c_int
+    L.plb_comm_pieces.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_int64)]
     L.plb_broadcast_params.restype = C.c_int
     L.plb_broadcast_params.argtypes = [vp, i32, vp]
     L.plb_set_grad_overlap.restype = C.c_int

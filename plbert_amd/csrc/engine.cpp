@@ -49,7 +49,8 @@ std::vector<hipEvent_t> g_pool;
 const char* const kClassNames[PLB_K_NCLASS] = {
     "gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32", "gemm_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv",
     "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "reduce_slabs", "gather_scatter_rows", "cross_entropy",
-    "adamw", "cast_transpose", "token_ce", "gemm_nt_ce", "gemm_nt_small", "fp8_quantize", "attn_bwd"};
+    "adamw", "cast_transpose", "token_ce", "gemm_nt_ce", "gemm_nt_small", "fp8_quantize", "attn_bwd", "gemm_nt_fp8",
+    "gemm_nt_gelu_fp8", "gemm_nt_gelubwd_fp8"};
 hipEvent_t prof_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
@@ -193,6 +194,7 @@ struct PlbEngine {
   bool comm_pending = false;    // pieces were issued: plb_allreduce_grads / plb_adamw_step must join ev_comm_done
   bool grads_reduced = false;   // the gradients of the last loss call have been all-reduced
   int64_t piece_floats = 0;     // floats submitted as pieces by the current loss call (must add up to the gradient range)
+  int32_t piece_count = 0;      // collectives the last step issued (pieces by the loss call + in-stream all-reduces)
   // bound buffers
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
   char* ws = nullptr;
@@ -754,6 +756,7 @@ static int reduce_piece(PlbEngine* e, int64_t a, int64_t b, hipStream_t after) {
   if (rc != kNcclSuccess) return fail("ncclAllReduce: %s", g_rccl.GetErrorString(rc));
   e->comm_pending = true;
   e->piece_floats += b - a;
+  e->piece_count += 1;
   return 0;
 }
 static bool overlapping(const PlbEngine* e) { return e->comm && e->overlap; }
@@ -788,10 +791,15 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
   const int T = B * S;
   const int64_t Tp = rup(T, 128);
   if (backward) {
+    // All-reduce pieces of a PREVIOUS backward that nobody joined (two plb_loss_fwd_bwd calls with no plb_allreduce_grads /
+    // plb_adamw_step between them: gradient probing, a caller that skips a step on a bad loss) still read and write the
+    // gradient buffer on the communication stream: this call's kernels must not touch it before they have finished.
+    if (e->comm && e->comm_pending) HIPTRY(hipStreamWaitEvent(s, e->ev_comm_done, 0));
     e->tok_grads_live = token_targets != nullptr;
     e->comm_pending = false;
     e->grads_reduced = false;
     e->piece_floats = 0;
+    e->piece_count = 0;
   }
   if (n_masked == 0 && !token_targets) {  // train.py:129 — zero loss, nothing to back-propagate
     HIPTRY(hipMemsetAsync(loss, 0, sizeof(float), s));
@@ -1176,6 +1184,13 @@ extern "C" int plb_comm_info(const PlbEngine* e, int32_t* rank, int32_t* world, 
   return 0;
 }
 
+extern "C" int plb_comm_pieces(const PlbEngine* e, int32_t* collectives, int64_t* floats) {
+  if (!e) return fail("plb_comm_pieces: null engine");
+  if (collectives) *collectives = e->piece_count;
+  if (floats) *floats = e->piece_floats;
+  return 0;
+}
+
 extern "C" int plb_set_grad_overlap(PlbEngine* e, int32_t overlap) {
   if (!e) return fail("plb_set_grad_overlap: null engine");
   e->overlap = overlap != 0;
@@ -1203,9 +1218,13 @@ extern "C" int plb_allreduce_grads(PlbEngine* e, void* stream) {
   }
   if (e->grads_reduced) return 0;
   int rc = g_rccl.AllReduce(e->grads, e->grads, (size_t)e->ptrain, kNcclFloat32, kNcclSum, e->comm, s);
+  e->piece_count = 1;
+  e->piece_floats = e->ptrain;
   if (rc == kNcclSuccess && e->tok_grads_live) {
     const int64_t o = e->poff[PLB_TOK_W];
     rc = g_rccl.AllReduce(e->grads + o, e->grads + o, (size_t)(e->ptotal - o), kNcclFloat32, kNcclSum, e->comm, s);
+    e->piece_count = 2;
+    e->piece_floats += e->ptotal - o;
   }
   if (rc != kNcclSuccess) return fail("ncclAllReduce: %s", g_rccl.GetErrorString(rc));
   e->grads_reduced = true;

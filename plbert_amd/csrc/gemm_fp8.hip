@@ -38,7 +38,7 @@ extern "C" int plb_launch_gemm_nt_fp8(const PlbGemmNT* p, int act, int a_bf8, hi
   if (act == 0 && p->N % 384 == 0) tile = 384;
   else if (p->N % 256 == 0) tile = 1256;
   else return 3;
-  const int cls = act == 1 ? PLB_K_GEMM_NT_GELU : act == 2 ? PLB_K_GEMM_NT_GELUBWD : PLB_K_GEMM_NT;
+  const int cls = act == 1 ? PLB_K_GEMM_NT_GELU_FP8 : act == 2 ? PLB_K_GEMM_NT_GELUBWD_FP8 : PLB_K_GEMM_NT_FP8;
   const double mnk = (double)p->M * p->N * p->K;
   const double bytes = ((double)p->M * p->K + (double)p->N * p->K) + (double)p->M * p->N * (act == 1 ? 4 : 2) +
                        (p->res ? 2.0 * p->M * p->N : 0.0) + (act == 2 ? 2.0 * p->M * p->N : 0.0) +

@@ -12,7 +12,9 @@ extern "C" {
 enum PlbKernelClass {
   PLB_K_GEMM_NT = 0, PLB_K_GEMM_NT_GELU, PLB_K_GEMM_NT_GELUBWD, PLB_K_GEMM_NT_F32, PLB_K_GEMM_TN,
   PLB_K_ATTN_FWD, PLB_K_ATTN_BWD_DQ, PLB_K_ATTN_BWD_DKV, PLB_K_LN_FWD, PLB_K_LN_BWD, PLB_K_EMBED_FWD,
-  PLB_K_EMBED_BWD, PLB_K_COLSUM, PLB_K_REDUCE, PLB_K_ROWS, PLB_K_CE, PLB_K_ADAMW, PLB_K_CAST, PLB_K_TOKEN_CE, PLB_K_GEMM_NT_CE, PLB_K_GEMM_NT_SMALL, PLB_K_FP8, PLB_K_ATTN_BWD, PLB_K_NCLASS
+  PLB_K_EMBED_BWD, PLB_K_COLSUM, PLB_K_REDUCE, PLB_K_ROWS, PLB_K_CE, PLB_K_ADAMW, PLB_K_CAST, PLB_K_TOKEN_CE, PLB_K_GEMM_NT_CE, PLB_K_GEMM_NT_SMALL, PLB_K_FP8, PLB_K_ATTN_BWD,
+  PLB_K_GEMM_NT_FP8, PLB_K_GEMM_NT_GELU_FP8, PLB_K_GEMM_NT_GELUBWD_FP8,  // the fp8 launches: priced against the fp8 MFMA peak
+  PLB_K_NCLASS
 };
 int plb_prof_begin(int cls, hipStream_t s, double flops, double bytes);
 void plb_prof_end(int tok, hipStream_t s);

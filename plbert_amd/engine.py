@@ -179,6 +179,12 @@ class HipEngine:
         _lib.check(self.L.plb_comm_info(self.handle, C.byref(r), C.byref(w), C.byref(v)), "plb_comm_info")
         return int(r.value), int(w.value), int(v.value)
 
+    def comm_pieces(self):
+        """(collectives, floats) of the last step's gradient exchange."""
+        n, f = C.c_int32(), C.c_int64()
+        _lib.check(self.L.plb_comm_pieces(self.handle, C.byref(n), C.byref(f)), "plb_comm_pieces")
+        return int(n.value), int(f.value)
+
     def comm_destroy(self):
         with torch.cuda.device(self.device):
             self.L.plb_comm_destroy(self.handle)

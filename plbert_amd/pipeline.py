@@ -48,9 +48,18 @@ class DeviceFeeder:
 
     ``for batch in DeviceFeeder(loader, device): trainer.step(batch)``. Call ``release(batch)`` after enqueuing the
     work that reads a batch if you hold more than one batch at a time; plain iteration releases the previous batch
-    when the next one is requested."""
+    when the next one is requested.
 
-    def __init__(self, loader, device=None, depth=2, vocab_size=None, validate=True, word_separator=None, prefetch=4):
+    ``draw_budget`` (None = unlimited): how many batches the producer thread may draw from the loader; ``grant(n)`` adds
+    n. The reference's masking draws the process-global ``random`` / ``numpy.random`` streams inside ``__getitem__`` and
+    runs validation BETWEEN two training batches (train.py:369-373), so a producer that prefetches past a validation
+    point — or runs beside the validation loader's producer — changes which random numbers each batch sees, run to run.
+    A caller that validates mid-epoch grants exactly the batches up to the next validation (``run.train_loop``), which
+    reproduces the reference's draw order. One feeder object may be iterated many times (epochs, repeated validation): its
+    pinned buffers, device slots and copy stream persist."""
+
+    def __init__(self, loader, device=None, depth=2, vocab_size=None, validate=True, word_separator=None, prefetch=4,
+                 draw_budget=None):
         self.loader = loader
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.depth = max(2, int(depth))
@@ -62,6 +71,13 @@ class DeviceFeeder:
         self._ready = [torch.cuda.Event() for _ in range(self.depth)]
         self._free = [torch.cuda.Event() for _ in range(self.depth)]
         self._prev = None
+        self._limited = draw_budget is not None
+        self._budget = threading.Semaphore(int(draw_budget or 0))
+
+    def grant(self, n):
+        """Allow the producer to draw ``n`` more batches (only meaningful with ``draw_budget``)."""
+        for _ in range(int(n)):
+            self._budget.release()
 
     # ---- producer thread: DataLoader -> packed host arrays -------------------------------------------------
     def _put(self, q, item, stop):
@@ -75,7 +91,18 @@ class DeviceFeeder:
 
     def _produce(self, q, stop):
         try:
-            for item in self.loader:
+            it = iter(self.loader)
+            while True:
+                if self._limited:
+                    while not self._budget.acquire(timeout=0.2):
+                        if stop.is_set():
+                            return
+                try:
+                    item = next(it)
+                except StopIteration:
+                    if self._limited:
+                        self._budget.release()      # nothing was drawn: the unit belongs to the next epoch's first batch
+                    break
                 if not self._put(q, self._host_pack(item), stop):
                     return
             self._put(q, None, stop)
@@ -117,7 +144,14 @@ class DeviceFeeder:
         if self._pinned[k] is None or self._pinned[k].numel() < n:
             cap = max(n * 2, 1 << 16)
             self._pinned[k] = torch.empty(cap, dtype=torch.uint8).pin_memory()
-            self._slots[k] = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            cur = torch.cuda.current_stream(self.device)
+            if self._slots[k] is not None:
+                self._slots[k].record_stream(cur)   # the step still reading the old slot keeps its memory until it is done
+            # the slot belongs to the COPY stream's allocator pool: allocated under the compute stream it could alias a
+            # block that a step still in flight has just freed, and the copy below does not wait for that step
+            with torch.cuda.stream(self.copy_stream):
+                self._slots[k] = torch.empty(cap, dtype=torch.uint8, device=self.device)
+            self._slots[k].record_stream(cur)       # read by the compute stream from now on
         self._free[k].synchronize()                 # the step that last read this slot (and its pinned twin) is done
         self._pinned[k][:n].numpy()[:] = buf
         with torch.cuda.stream(self.copy_stream):

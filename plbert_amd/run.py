@@ -160,14 +160,25 @@ def initialize_model(config, log_dir, resuming, device=None, max_batch=None):
     return trainer, current_step
 
 
-def _batches(loader, trainer, device_masking, word_separator):
+def _feeder(loader, trainer, word_separator, budget=None):
+    """ONE DeviceFeeder per (trainer, loader): its pinned buffers, device slots and copy stream are created once (a fresh
+    set per validation pass was measured as tens of slow steps after every pass)."""
+    from .pipeline import DeviceFeeder
+    cache = trainer.__dict__.setdefault("_feeders", {})
+    f = cache.get(id(loader))
+    if f is None:
+        f = cache[id(loader)] = DeviceFeeder(loader, device=trainer.engine.device, vocab_size=trainer.engine.cfg.vocab_size,
+                                             word_separator=word_separator, draw_budget=budget)
+    return f
+
+
+def _batches(loader, trainer, device_masking, word_separator, budget=None):
     """Collated batches of the loader as device-resident StagedBatch objects: this rank's contiguous slice of every
-    global batch (accelerate's split_batches=True), copies overlapped with compute (DeviceFeeder) on one GPU."""
+    global batch (accelerate's split_batches=True), copies overlapped with compute (DeviceFeeder) on one GPU.
+    ``budget``: see DeviceFeeder.draw_budget (the training loader: draws are granted up to the next validation)."""
     rank, world = world_info()
     if world == 1:
-        from .pipeline import DeviceFeeder
-        yield from DeviceFeeder(loader, device=trainer.engine.device, vocab_size=trainer.engine.cfg.vocab_size,
-                                word_separator=word_separator)
+        yield from _feeder(loader, trainer, word_separator, budget)
         return
     for batch in loader:
         lab, msk, lens, idx = shard_batch((np.asarray(batch[0]), np.asarray(batch[1]), batch[2], batch[3]), rank, world,
@@ -192,9 +203,18 @@ def train_loop(trainer, train_loader, val_loader, current_step, num_steps, save_
     window = deque(maxlen=log_interval)
     epoch = 0
     log(val_phoneme_loss=validate(trainer, val_loader, device_masking, word_separator), step=current_step, epoch=epoch)
+    single = world_info()[1] == 1
+
+    def grant():
+        # the training producer may draw up to the next validation point and no further: the validation pass then sees the
+        # global masking streams exactly where the reference's single-threaded loop leaves them (train.py:369-373)
+        if single:
+            _feeder(train_loader, trainer, word_separator, 0).grant(save_interval - current_step % save_interval)
+
+    grant()
     while epoch < max_epochs:
         epoch += 1
-        for batch in _batches(train_loader, trainer, device_masking, word_separator):
+        for batch in _batches(train_loader, trainer, device_masking, word_separator, 0):
             loss = float(trainer.step(batch).item())            # the reference syncs here too (loss.item(), train.py:395)
             current_step += 1
             window.append(loss)
@@ -206,6 +226,7 @@ def train_loop(trainer, train_loader, val_loader, current_step, num_steps, save_
                 save_checkpoint(trainer, current_step, log_dir, epoch, main)
                 log(val_phoneme_loss=validate(trainer, val_loader, device_masking, word_separator), step=current_step,
                     epoch=epoch)
+                grant()
             if current_step >= num_steps:
                 return current_step, epoch
     return current_step, epoch
