@@ -748,8 +748,16 @@ static int backward_tail(PlbEngine* e, const int64_t* masked_ids, bf16_t* dy, in
 
 // ---- gradient exchange pieces ---------------------------------------------------------------------------------
 // One sum all-reduce of grads[a, b) on the communication stream, ordered after everything enqueued on `after` so far.
+static int g_debug_skip_piece = -1;   // test hook (plb_debug_skip_piece): drop the n-th piece of a loss call
+extern "C" void plb_debug_skip_piece(int index) { g_debug_skip_piece = index; }
+
 static int reduce_piece(PlbEngine* e, int64_t a, int64_t b, hipStream_t after) {
   if (!e->comm || b <= a) return 0;
+  if (g_debug_skip_piece >= 0 && e->piece_count == g_debug_skip_piece) {  // what a forgotten tensor looks like
+    g_debug_skip_piece = -1;
+    e->piece_count += 1;
+    return 0;
+  }
   HIPTRY(hipEventRecord(e->ev_piece, after));
   HIPTRY(hipStreamWaitEvent(e->comm_stream, e->ev_piece, 0));
   const int rc = g_rccl.AllReduce(e->grads + a, e->grads + a, (size_t)(b - a), kNcclFloat32, kNcclSum, e->comm, e->comm_stream);

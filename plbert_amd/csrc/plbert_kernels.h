@@ -150,6 +150,10 @@ int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream);
 // S <= 512 (attn_bwd_fused.hip: 5 products, dQ complete inside the workgroup; delta is not written)
 int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream);
 int plb_launch_attn_bwd_fused(const PlbAttn* p, hipStream_t stream);
+// Test hook of the gradient exchange (tests/test_gpu_comm_fake_rccl.py): the next loss call leaves out its index-th
+// all-reduce piece, as a forgotten tensor would; the call must then fail in pieces_done() instead of training on a
+// gradient range that was never exchanged.
+void plb_debug_skip_piece(int index);
 void plb_set_attn_bwd_fused(int on);
 
 // Loss rows: row r of the gathered matrix is token rows[r]

@@ -1,0 +1,155 @@
+"""The engine's OWN gradient exchange at world size 2 (-m gpu). RCCL refuses two ranks on one device and the test box has
+one GPU, so the piecewise protocol of csrc/engine.cpp (pieces issued inside plb_loss_fwd_bwd on the communication
+stream, the zero-masked rank that must issue the identical collective sequence, the dual-head token piece, the coverage
+check of pieces_done) had only run where ncclAllReduce is the identity. tests/fake_rccl.cpp is a stand-in library with
+RCCL's seven entry points — stream-ordered collectives over POSIX shared memory between processes that share the GPU —
+loaded through PLBERT_RCCL_LIB. Checked against the same two ranks exchanging through torch.distributed / gloo
+(dist.GradReducer, pinned to DDP's semantics by tests/test_gpu_dist_two_ranks.py): replicas must be bit-identical.
+Reference: the DDP bucketed all-reduce the reference gets from accelerate (train.py:218-221, 356)."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fake_lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out,
+                        os.path.join(ROOT, "tests", "fake_rccl.cpp"), "-lrt", "-lpthread"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return out
+
+
+def _setup(num_tokens):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import plbert_amd
+
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, embedding_size=64, hidden_size=256, num_attention_heads=4,
+                                  intermediate_size=512, num_hidden_layers=3, max_position_embeddings=512)
+    labels, masked, lengths, idx = plbert_amd.synthetic_batch(4, 64, seed=3)
+    tok = np.random.RandomState(5).randint(0, max(num_tokens, 1), size=(4, 64)).astype(np.int64) if num_tokens else None
+    return plbert_amd, cfg, (labels, masked, lengths, idx), tok
+
+
+def _worker(rank, world, port, lib, num_tokens, empty_rank, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PLBERT_RCCL_LIB=lib, FAKE_RCCL_TIMEOUT_S="60")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    plbert_amd, cfg, batch, tok = _setup(num_tokens)
+    from plbert_amd.dist import shard_batch
+    from plbert_amd.train import PLBertTrainer
+
+    torch.cuda.set_device(0)
+    labels, masked, lengths, idx = batch
+    if empty_rank is not None:  # this rank's shard holds no masked phoneme: zero loss, zero gradients, SAME collectives
+        per = len(lengths) // world
+        for b in range(empty_rank * per, (empty_rank + 1) * per):
+            idx[b] = []
+            masked[b] = labels[b]
+    lab, msk, lens, ix = shard_batch((labels, masked, lengths, idx), rank, world)
+    tk = tok[rank * 2:(rank + 1) * 2] if tok is not None else None
+    res = {}
+    for mode, overlap in (("torch", True), ("rccl", True), ("rccl", False)):
+        tr = PLBertTrainer(cfg, 188, max_batch=2, max_seq=64, lr=1e-3, seed=11, num_tokens=num_tokens, comm=mode,
+                           overlap=overlap)
+        assert tr.world == world and tr.comm == mode
+        if mode == "rccl":
+            assert tr.engine.comm_info() == (rank, world, 29999)          # the stand-in, not a real RCCL
+        b = tr.stage_batch(lab, msk, lens, ix, token_ids=tk)
+        losses = [float(tr.step(b).item()) for _ in range(3)]
+        torch.cuda.synchronize()
+        pieces = tr.engine.comm_pieces() if mode == "rccl" else None
+        res[(mode, overlap)] = (losses, tr.engine.params.cpu().numpy().copy(), pieces)
+        if mode == "rccl":
+            tr.engine.comm_destroy()
+        del tr
+    L = C.CDLL(lib)
+    L.fake_rccl_errors.restype = C.c_uint
+    out[rank] = (res, int(L.fake_rccl_errors()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world2(lib, num_tokens=0, empty_rank=None):
+    port = 29800 + (os.getpid() % 1500)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(2, port, lib, num_tokens, empty_rank, out), nprocs=2, join=True)
+        return dict(out)
+
+
+def _check(res, expect_pieces_overlap):
+    for r in (0, 1):
+        assert res[r][1] == 0, "fake_rccl saw mismatched collectives or a time-out"
+    ref0, ref1 = res[0][0][("torch", True)], res[1][0][("torch", True)]
+    assert np.array_equal(ref0[1], ref1[1])                                  # gloo replicas agree (DDP semantics pinned elsewhere)
+    for key in (("rccl", True), ("rccl", False)):
+        for r in (0, 1):
+            losses, params, pieces = res[r][0][key]
+            assert losses == res[r][0][("torch", True)][0], (key, r)         # local losses: the exchange does not touch them
+            assert np.array_equal(params, ref0[1]), (key, r)                 # bit-identical to the gloo exchange, on both ranks
+            assert pieces[0] == (expect_pieces_overlap if key[1] else expect_pieces_overlap - 7), (key, pieces)
+
+
+def test_piecewise_exchange_world2_matches_gloo(fake_lib):
+    """Overlapped (8 pieces inside plb_loss_fwd_bwd) and serial (one all-reduce in plb_allreduce_grads) forms."""
+    _check(_run_world2(fake_lib), expect_pieces_overlap=8)
+
+
+def test_zero_masked_rank_issues_the_same_collectives(fake_lib):
+    """Rank 1's shard has no masked phoneme: its loss call takes the early-return path (train.py:129) and must replay the
+    8 ranges in the order a regular step issues them — a different sequence would deadlock or, worse, sum mismatched
+    ranges; the stand-in checks (kind, count) of every collective across the ranks."""
+    res = _run_world2(fake_lib, empty_rank=1)
+    _check(res, expect_pieces_overlap=8)
+    assert res[1][0][("rccl", True)][0] == [0.0, 0.0, 0.0]
+
+
+def test_dual_head_token_piece_world2(fake_lib):
+    """Dual-head step: the token head's gradients travel as a ninth piece (two all-reduces in the serial form)."""
+    _check(_run_world2(fake_lib, num_tokens=512), expect_pieces_overlap=9)
+
+
+def test_forgotten_piece_is_caught(fake_lib):
+    """A piece left out of the exchange (plb_debug_skip_piece) makes the loss call FAIL in pieces_done(): at world 1 a
+    forgotten tensor would otherwise go unnoticed for ever (the all-reduce is the identity there)."""
+    code = f"""
+import os, sys
+sys.path.insert(0, {ROOT!r})
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='{29900 + os.getpid() % 90}', PLBERT_RCCL_LIB={fake_lib!r})
+import torch, torch.distributed as dist
+import plbert_amd
+from plbert_amd import _lib
+from plbert_amd.train import PLBertTrainer
+dist.init_process_group('gloo', rank=0, world_size=1)
+cfg = plbert_amd.AlbertConfig(vocab_size=188, embedding_size=64, hidden_size=256, num_attention_heads=4,
+                              intermediate_size=512, num_hidden_layers=2, max_position_embeddings=512)
+labels, masked, lens, idx = plbert_amd.synthetic_batch(2, 64, seed=3)
+tr = PLBertTrainer(cfg, 188, max_batch=2, max_seq=64, lr=1e-3, seed=1, force_collectives=True, comm='rccl', overlap=True)
+b = tr.stage_batch(labels, masked, lens, idx)
+tr.step(b); torch.cuda.synchronize()
+assert tr.engine.comm_pieces()[0] == 8
+L = _lib.lib()
+L.plb_debug_skip_piece.argtypes = [__import__('ctypes').c_int]
+L.plb_debug_skip_piece(3)
+try:
+    tr.step(b)
+except RuntimeError as ex:
+    assert 'gradient exchange covered' in str(ex), ex
+    print('CAUGHT')
+else:
+    print('MISSED')
+"""
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert "CAUGHT" in r.stdout, r.stdout[-2000:]
