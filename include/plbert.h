@@ -177,6 +177,11 @@ int plb_comm_unique_id(uint8_t id[PLB_COMM_ID_BYTES]);
 int plb_comm_init(PlbEngine* e, const uint8_t id[PLB_COMM_ID_BYTES], int32_t rank, int32_t world);
 int plb_comm_destroy(PlbEngine* e);
 int plb_comm_info(const PlbEngine* e, int32_t* rank, int32_t* world, int32_t* rccl_version);
+/* Diagnostic, SYNCHRONISES the device: hand-offs between the column tiles of the LayerNorm-in-GEMM launches (csrc/
+ * gemm_ln.hip) that timed out since the engine was bound. Must be 0: a non-zero count means a launch's tiles were not
+ * co-resident long enough and its LayerNorm statistics are invalid (the wait is bounded so that such a launch ends
+ * instead of hanging the device). No reference counterpart (the reference's LayerNorm is torch's kernel). */
+int plb_status(PlbEngine* e, int32_t* ln_exchange_timeouts);
 /* What the last training step exchanged: the number of collectives it issued (8 pieces for the reference's phoneme-only
  * step with overlap on, 1 with overlap off; one more after a dual-head step) and the floats they covered. The reference
  * has no counterpart (DDP's bucket count is internal to torch, train.py:218-221); a caller logs it to see which form of

@@ -54,7 +54,7 @@ PUBLIC_SYMBOLS = [
     "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
     "plb_sync_weights", "plb_forward", "plb_pooler", "plb_loss_fwd_bwd", "plb_loss_fwd", "plb_loss_fwd_bwd_dual", "plb_adamw_step",
     "plb_set_fp8", "plb_fp8_state", "plb_token_head_steps", "plb_set_token_head_steps", "plb_comm_unique_id", "plb_comm_init", "plb_comm_destroy",
-    "plb_comm_info", "plb_comm_pieces", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
+    "plb_comm_info", "plb_comm_pieces", "plb_status", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
     "plb_mask_batch", "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
 ]
 
@@ -81,6 +81,8 @@ class PlbGemmNT(C.Structure):
         ("ce_tlogit", C.c_void_p), ("ce_lse", C.c_void_p), ("ce_w", C.c_void_p),
         ("deq_a", C.c_void_p), ("deq_b", C.c_void_p), ("C8", C.c_void_p), ("ldc8", C.c_int), ("q_scale", C.c_void_p),
         ("q_amax", C.c_void_p), ("c8_bf8", C.c_int),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p),
+        ("ln_eps", C.c_float), ("ln_xchg", C.c_void_p), ("ln_err", C.c_void_p),
     ]
 
 
@@ -183,6 +185,8 @@ def lib():
     L.plb_comm_destroy.argtypes = [vp]
     L.plb_comm_info.restype = C.c_int
     L.plb_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.plb_status.restype = C.c_int
+    L.plb_status.argtypes = [vp, C.POINTER(i32)]
     L.plb_comm_pieces.restype = C.c_int
     L.plb_comm_pieces.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_int64)]
     L.plb_broadcast_params.restype = C.c_int
@@ -222,6 +226,8 @@ def lib():
     L.plb_launch_reduce_slabs.argtypes = [vp, C.c_int, C.c_size_t, vp, C.c_int, vp]
     L.plb_launch_attn_fwd.restype = C.c_int
     L.plb_launch_attn_fwd.argtypes = [C.POINTER(PlbAttn), vp]
+    L.plb_launch_gemm_nt_ln.restype = C.c_int
+    L.plb_launch_gemm_nt_ln.argtypes = [C.POINTER(PlbGemmNT), C.c_int, vp]
     L.plb_launch_attn_bwd.restype = C.c_int
     L.plb_launch_attn_bwd.argtypes = [C.POINTER(PlbAttn), vp]
     L.plb_launch_attn_bwd_fused.restype = C.c_int

@@ -50,7 +50,7 @@ const char* const kClassNames[PLB_K_NCLASS] = {
     "gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32", "gemm_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv",
     "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "reduce_slabs", "gather_scatter_rows", "cross_entropy",
     "adamw", "cast_transpose", "token_ce", "gemm_nt_ce", "gemm_nt_small", "fp8_quantize", "attn_bwd", "gemm_nt_fp8",
-    "gemm_nt_gelu_fp8", "gemm_nt_gelubwd_fp8"};
+    "gemm_nt_gelu_fp8", "gemm_nt_gelubwd_fp8", "gemm_nt_lnfwd", "gemm_nt_lnbwd"};
 hipEvent_t prof_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
@@ -176,6 +176,10 @@ struct PlbEngine {
   int64_t slab_floats;
   int64_t ws_bytes;
   int ln_blocks, emb_blocks;
+  int part_rows = 0;            // rows per layer reserved in o_part1 / o_part2
+  int part_rows_used = 0;       // rows per layer the last backward wrote
+  int ln_fuse = 3;              // bit 0: LayerNorm forward in the producing GEMM's epilogue, bit 1: LayerNorm backward
+  int64_t o_lnx = 0, o_lnerr = 0;
   // fp8 mode (plb_set_fp8): transient 1-byte images of the fp8 GEMMs' activation / gradient operands, fp8 weight copies
   // and the per-(site, layer) delayed-scaling state [amax | scale | deq] (+ one entry per weight copy)
   bool fp8_on = false, fp8_ready = false, fp8_bwd_ready = false, fp8_wstale = true;
@@ -297,6 +301,10 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   e->ln_blocks = 512;
   if (const char* v = getenv("PLBERT_LN_BLOCKS")) { const int n = atoi(v); if (n >= 64 && n <= 4096) e->ln_blocks = n; }
   e->emb_blocks = 2048;
+  // LayerNorm in the GEMM epilogues (gemm_ln.hip): PLBERT_LN_FUSE = off | fwd | bwd | both (default both)
+  if (const char* v = getenv("PLBERT_LN_FUSE"))
+    e->ln_fuse = !strcmp(v, "off") ? 0 : !strcmp(v, "fwd") ? 1 : !strcmp(v, "bwd") ? 2 : 3;
+  e->part_rows = e->ln_blocks > (int)(2 * Tp / 128) ? e->ln_blocks : (int)(2 * Tp / 128);
   Carve cv;
   // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes
   e->o_wbf = cv.take((e->ptotal + 256 * (H > I ? H : I)) * 2);
@@ -322,6 +330,9 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   e->o_lse = cv.take(Ls * stat);
   e->o_mean1 = cv.take(Ls * Tp * 4); e->o_rstd1 = cv.take(Ls * Tp * 4);
   e->o_mean2 = cv.take(Ls * Tp * 4); e->o_rstd2 = cv.take(Ls * Tp * 4);
+  // exchange granules of the LayerNorm epilogues: [Tp/128][nbn][nbn][128][2] x 8 B, nbn <= 4 column tiles; zero between launches
+  e->o_lnx = cv.take((Tp / 128) * 16 * 128 * 2 * 8);
+  e->o_lnerr = cv.take(256);
   if (tr) {
     e->o_delta = cv.take(stat);
     // backward stash (operands of the batched dW GEMMs)
@@ -357,8 +368,8 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
     }
     e->slab_floats = slab;
     e->o_slab = cv.take(slab * 4);
-    e->o_part1 = cv.take(L * e->ln_blocks * 3 * H * 4);  // per LN-backward block: dgamma | dbeta | column sums of dx
-    e->o_part2 = cv.take(L * e->ln_blocks * 3 * H * 4);
+    e->o_part1 = cv.take(L * e->part_rows * 3 * H * 4);  // per LN-backward block: dgamma | dbeta | column sums of dx
+    e->o_part2 = cv.take(L * e->part_rows * 3 * H * 4);
     e->o_parte = cv.take((int64_t)e->emb_blocks * 2 * E * 4);
     e->o_dxe = cv.take(Tp * E * 4);
     e->o_ducol = cv.take(L * (2 * Tp / 128) * I * 4);  // column-sum partials of dU from the GEMM epilogue
@@ -585,6 +596,18 @@ static int gemm_nt_any(PlbGemmNT* g, int act, const F8Op* f8, hipStream_t s) {
   return plb_launch_gemm_nt_fp8(&q, act, f8->a_bf8, s);
 }
 
+// LayerNorm in the epilogue of the GEMM that produces its input (gemm_ln.hip): the shapes it exists for. Not in calls
+// that run the fp8 GEMMs (the LayerNorm kernels also write the fp8 images there); an fp8 CALIBRATION call computes in
+// bf16 and fuses like any bf16 call (it must equal the bf16 path bit for bit: tests/test_gpu_fp8.py).
+static bool ln_fusable(const PlbEngine* e, int64_t Tp, int bit, bool f8_call) {
+  const int H = e->H;
+  return (e->ln_fuse & bit) && !f8_call && Tp % 1024 == 0 && (H % 384 == 0 ? H / 384 : H % 256 == 0 ? H / 256 : 99) <= 4;
+}
+static void ln_fields(const PlbEngine* e, PlbGemmNT* g, const float* gamma, const float* beta, float* mean, float* rstd) {
+  g->ln_gamma = gamma; g->ln_beta = beta; g->ln_mean = mean; g->ln_rstd = rstd; g->ln_eps = e->c.layer_norm_eps;
+  g->ln_xchg = e->at<unsigned long long>(e->o_lnx); g->ln_err = e->at<unsigned int>(e->o_lnerr);
+}
+
 // Embeddings + L applications of the shared layer. stash: keep every layer's activations (training)
 // or reuse the layer-0 slots (inference). Returns the final hidden buffer in *xout.
 // fp8 mode: the QKV and the two FFN GEMMs run on e4m3 images — the LayerNorm kernels and the gelu epilogue write them
@@ -649,14 +672,21 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     memset(&g, 0, sizeof(g));
     g.A = ctx; g.lda = H; g.B = e->wbf(PLB_DENSE_W); g.ldb = H; g.M = (int)Tp; g.N = H; g.K = H; g.Mstore = (int)Tp;
     g.bias = e->par(PLB_DENSE_B); g.res = x; g.ldr = H; g.C = pre1; g.ldc = H;
-    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    const bool fuse_f = ln_fusable(e, Tp, 1, f8);
     PlbLayerNorm ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.beta = e->par(PLB_LN1_B); ln.eps = e->c.layer_norm_eps;
-    ln.y = a; ln.ldy = H; ln.T = T; ln.H = H;
-    ln.mean = e->at<float>(e->o_mean1) + sl * Tp; ln.rstd = e->at<float>(e->o_rstd1) + sl * Tp;
-    if (f8) { ln.out8 = a8; ln.ld8 = H; ln.q_scale = f8_scale(e, sA); ln.q_amax = f8_amax(e, sA); }
-    TRY(plb_launch_ln_fwd(&ln, s));
+    if (fuse_f) {  // dense + residual + LayerNorm in one launch
+      g.C2 = a; g.ldc2 = H;
+      ln_fields(e, &g, e->par(PLB_LN1_W), e->par(PLB_LN1_B), e->at<float>(e->o_mean1) + sl * Tp, e->at<float>(e->o_rstd1) + sl * Tp);
+      TRY(plb_launch_gemm_nt_ln(&g, 5, s));
+    } else {
+      TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+      memset(&ln, 0, sizeof(ln));
+      ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.beta = e->par(PLB_LN1_B); ln.eps = e->c.layer_norm_eps;
+      ln.y = a; ln.ldy = H; ln.T = T; ln.H = H;
+      ln.mean = e->at<float>(e->o_mean1) + sl * Tp; ln.rstd = e->at<float>(e->o_rstd1) + sl * Tp;
+      if (f8) { ln.out8 = a8; ln.ld8 = H; ln.q_scale = f8_scale(e, sA); ln.q_amax = f8_amax(e, sA); }
+      TRY(plb_launch_ln_fwd(&ln, s));
+    }
     if (calib) TRY(plb_launch_amax(a, 1, (size_t)T, H, H, f8_amax(e, sA), s));
     // FFN: u = a W1^T + b1, g = gelu_new(u); pre2 = g W2^T + b2 + a
     memset(&g, 0, sizeof(g));
@@ -670,16 +700,22 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     g.A = gl; g.lda = I; g.B = e->wbf(PLB_FFNO_W); g.ldb = I; g.M = (int)Tp; g.N = H; g.K = I; g.Mstore = (int)Tp;
     g.bias = e->par(PLB_FFNO_B); g.res = a; g.ldr = H; g.C = pre2; g.ldc = H;
     F8Op o2 = {g8, e->at<uint8_t>(e->o_w28), f8_deq(e, sG), f8_deq(e, f8_w(e, F8W_2)), 0};
-    TRY(gemm_nt_any(&g, 0, f8 ? &o2 : nullptr, s));
-    memset(&ln, 0, sizeof(ln));
-    ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.beta = e->par(PLB_LN2_B); ln.eps = e->c.layer_norm_eps;
-    ln.y = y; ln.ldy = H; ln.T = T; ln.H = H;
-    ln.mean = e->at<float>(e->o_mean2) + sl * Tp; ln.rstd = e->at<float>(e->o_rstd2) + sl * Tp;
-    if (f8 && l + 1 < L) {  // the next application's input image
-      const int sN = f8_site(e, F8_X, l + 1);
-      ln.out8 = x8; ln.ld8 = H; ln.q_scale = f8_scale(e, sN); ln.q_amax = f8_amax(e, sN);
+    if (fuse_f) {  // FFN output + residual + LayerNorm in one launch
+      g.C2 = y; g.ldc2 = H;
+      ln_fields(e, &g, e->par(PLB_LN2_W), e->par(PLB_LN2_B), e->at<float>(e->o_mean2) + sl * Tp, e->at<float>(e->o_rstd2) + sl * Tp);
+      TRY(plb_launch_gemm_nt_ln(&g, 5, s));
+    } else {
+      TRY(gemm_nt_any(&g, 0, f8 ? &o2 : nullptr, s));
+      memset(&ln, 0, sizeof(ln));
+      ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.beta = e->par(PLB_LN2_B); ln.eps = e->c.layer_norm_eps;
+      ln.y = y; ln.ldy = H; ln.T = T; ln.H = H;
+      ln.mean = e->at<float>(e->o_mean2) + sl * Tp; ln.rstd = e->at<float>(e->o_rstd2) + sl * Tp;
+      if (f8 && l + 1 < L) {  // the next application's input image
+        const int sN = f8_site(e, F8_X, l + 1);
+        ln.out8 = x8; ln.ld8 = H; ln.q_scale = f8_scale(e, sN); ln.q_amax = f8_amax(e, sN);
+      }
+      TRY(plb_launch_ln_fwd(&ln, s));
     }
-    TRY(plb_launch_ln_fwd(&ln, s));
     *xout = y;
   }
   return 0;
@@ -941,6 +977,12 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
   bf16_t* dctx = e->at<bf16_t>(e->o_dctx);
   uint8_t* dp8 = e->at<uint8_t>(e->o_dp8);
   uint8_t* du8 = e->at<uint8_t>(e->o_du8);
+  // LayerNorm backward inside the dX GEMM that produces its output gradient (gemm_ln.hip). Rows of partials per layer:
+  // 2 per 128-row tile in the fused form (the one standalone launch left — LayerNorm 2 of the last application, whose
+  // output gradient comes from the head — then uses as many blocks), else the LayerNorm kernel's block count.
+  const bool fuse_b = ln_fusable(e, Tp, 2, f8);
+  const int prows = fuse_b ? (int)(2 * Tp / 128) : e->ln_blocks;
+  e->part_rows_used = prows;
   for (int l = L - 1; l >= 0; --l) {
     bf16_t* qkv = e->at<bf16_t>(e->o_qkv) + (int64_t)l * Tp * 3 * H;
     bf16_t* ctx = e->at<bf16_t>(e->o_ctx) + (int64_t)l * Tp * H;
@@ -953,13 +995,15 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     bf16_t* dpre2 = e->at<bf16_t>(e->o_dpre2) + (int64_t)l * Tp * H;
     const int sDP = f8_site(e, F8_DP, l), sDU = f8_site(e, F8_DU, l);
     PlbLayerNorm ln;
-    memset(&ln, 0, sizeof(ln));
-    ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
-    ln.mean = e->at<float>(e->o_mean2) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd2) + (int64_t)l * Tp;
-    ln.dy = dy; ln.lddy = H; ln.dx = dpre2; ln.lddx = H;
-    ln.partials = e->at<float>(e->o_part2) + (int64_t)l * e->ln_blocks * 3 * H; ln.nblocks = e->ln_blocks;
-    if (f8) { ln.out8 = dp8; ln.ld8 = H; ln.q_scale = f8_scale(e, sDP); ln.q_amax = f8_amax(e, sDP); }
-    TRY(plb_launch_ln_bwd(&ln, s));
+    if (!(fuse_b && l != L - 1)) {  // fused form: the dX GEMM of application l+1 wrote dpre2 of this one (see below)
+      memset(&ln, 0, sizeof(ln));
+      ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
+      ln.mean = e->at<float>(e->o_mean2) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd2) + (int64_t)l * Tp;
+      ln.dy = dy; ln.lddy = H; ln.dx = dpre2; ln.lddx = H;
+      ln.partials = e->at<float>(e->o_part2) + (int64_t)l * prows * 3 * H; ln.nblocks = prows;
+      if (f8) { ln.out8 = dp8; ln.ld8 = H; ln.q_scale = f8_scale(e, sDP); ln.q_amax = f8_amax(e, sDP); }
+      TRY(plb_launch_ln_bwd(&ln, s));
+    }
     if (calib) TRY(plb_launch_amax(dpre2, 1, (size_t)T, H, H, f8_amax(e, sDP), s));
     // dU = (dpre2 · W2) ∘ gelu'(u)
     memset(&g, 0, sizeof(g));
@@ -975,13 +1019,22 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     g.A = du; g.lda = I; g.B = e->at<bf16_t>(e->o_w1T); g.ldb = I; g.M = (int)Tp; g.N = H; g.K = I; g.Mstore = (int)Tp;
     g.res = dpre2; g.ldr = H; g.C = da; g.ldc = H;
     F8Op oa = {du8, e->at<uint8_t>(e->o_w1T8), f8_deq(e, sDU), f8_deq(e, f8_w(e, F8W_1T)), 1};
-    TRY(gemm_nt_any(&g, 0, f8 ? &oa : nullptr, s));
-    memset(&ln, 0, sizeof(ln));
-    ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
-    ln.mean = e->at<float>(e->o_mean1) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd1) + (int64_t)l * Tp;
-    ln.dy = da; ln.lddy = H; ln.dx = dpre1; ln.lddx = H;
-    ln.partials = e->at<float>(e->o_part1) + (int64_t)l * e->ln_blocks * 3 * H; ln.nblocks = e->ln_blocks;
-    TRY(plb_launch_ln_bwd(&ln, s));
+    if (fuse_b) {
+      // dA = dU · W1 + dpre2 is the gradient of LayerNorm 1's output: its backward runs in this GEMM's epilogue and dA
+      // is never stored (dpre1 = the gradient of the LayerNorm's input, + the dgamma | dbeta | bias-gradient partials)
+      g.C = dpre1; g.aux = pre1; g.ldaux = H;
+      g.colpart = e->at<float>(e->o_part1) + (int64_t)l * prows * 3 * H;
+      ln_fields(e, &g, e->par(PLB_LN1_W), nullptr, e->at<float>(e->o_mean1) + (int64_t)l * Tp, e->at<float>(e->o_rstd1) + (int64_t)l * Tp);
+      TRY(plb_launch_gemm_nt_ln(&g, 6, s));
+    } else {
+      TRY(gemm_nt_any(&g, 0, f8 ? &oa : nullptr, s));
+      memset(&ln, 0, sizeof(ln));
+      ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
+      ln.mean = e->at<float>(e->o_mean1) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd1) + (int64_t)l * Tp;
+      ln.dy = da; ln.lddy = H; ln.dx = dpre1; ln.lddx = H;
+      ln.partials = e->at<float>(e->o_part1) + (int64_t)l * prows * 3 * H; ln.nblocks = prows;
+      TRY(plb_launch_ln_bwd(&ln, s));
+    }
     // dCtx = dpre1 · Wd
     memset(&g, 0, sizeof(g));
     g.A = dpre1; g.lda = H; g.B = e->at<bf16_t>(e->o_wdT); g.ldb = H; g.M = (int)Tp; g.N = H; g.K = H; g.Mstore = (int)Tp;
@@ -999,7 +1052,17 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     memset(&g, 0, sizeof(g));
     g.A = dqkv; g.lda = 3 * H; g.B = e->at<bf16_t>(e->o_wqkvT); g.ldb = 3 * H; g.M = (int)Tp; g.N = H; g.K = 3 * H;
     g.Mstore = (int)Tp; g.res = dpre1; g.ldr = H; g.C = dy_other; g.ldc = H;
-    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    if (fuse_b && l > 0) {
+      // the gradient of this application's input is the gradient of LayerNorm 2's output of application l-1: that
+      // LayerNorm's backward runs here and writes dpre2 of application l-1 directly
+      g.C = e->at<bf16_t>(e->o_dpre2) + (int64_t)(l - 1) * Tp * H;
+      g.aux = e->at<bf16_t>(e->o_pre2) + (int64_t)(l - 1) * Tp * H; g.ldaux = H;
+      g.colpart = e->at<float>(e->o_part2) + (int64_t)(l - 1) * prows * 3 * H;
+      ln_fields(e, &g, e->par(PLB_LN2_W), nullptr, e->at<float>(e->o_mean2) + (int64_t)(l - 1) * Tp, e->at<float>(e->o_rstd2) + (int64_t)(l - 1) * Tp);
+      TRY(plb_launch_gemm_nt_ln(&g, 6, s));
+    } else {
+      TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    }
     bf16_t* tmp = dy; dy = dy_other; dy_other = tmp;
   }
   if (e->fp8_on) {  // this call's maxima become the next call's scales; a calibration call arms the fp8 path
@@ -1061,7 +1124,7 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   // 2.5 us per launch to save side-stream traffic that is hidden behind the weight-gradient GEMMs anyway.) The third block is the bias
   // gradient of the Linear that produced the LayerNorm's input (dense.bias = colsum(dpre1), ffn_output.bias =
   // colsum(dpre2)): no pass over the stacked gradients.
-  const size_t prow = (size_t)L * e->ln_blocks;
+  const size_t prow = (size_t)L * e->part_rows_used;
   TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch2, 64, s2));
   TRY(plb_launch_copy_cols(scratch2, 64, 3 * H, 2 * H, H, e->grd(PLB_DENSE_B), s2));
   TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch2, 64, s2));
@@ -1189,6 +1252,15 @@ extern "C" int plb_comm_info(const PlbEngine* e, int32_t* rank, int32_t* world, 
     if (g_rccl.ok) (void)g_rccl.GetVersion(&v);
     *rccl_version = v;
   }
+  return 0;
+}
+
+extern "C" int plb_status(PlbEngine* e, int32_t* ln_exchange_timeouts) {
+  if (!e || !e->ws) return fail("plb_status: engine not bound");
+  unsigned int v = 0;
+  HIPTRY(hipDeviceSynchronize());
+  HIPTRY(hipMemcpy(&v, e->at<unsigned int>(e->o_lnerr), sizeof(v), hipMemcpyDeviceToHost));
+  if (ln_exchange_timeouts) *ln_exchange_timeouts = (int32_t)v;
   return 0;
 }
 

@@ -1,0 +1,29 @@
+// LayerNorm fused into the epilogue of the GEMM that produces its input (gemm_nt_pipeline.h, ACT 5 / 6): the dense and
+// FFN-output projections of the shared layer (forward: AlbertAttention.LayerNorm / full_layer_layer_norm,
+// modeling_albert.py:196-200, 225-238) and the two dX GEMMs whose output is the gradient of a LayerNorm's output
+// (backward). A translation unit of its own so that the plain instantiations keep their register allocation.
+#include "gemm_nt_pipeline.h"
+
+extern "C" int plb_launch_gemm_nt_ln(const PlbGemmNT* p, int mode, hipStream_t stream) {
+  if (mode != 5 && mode != 6) return 1;
+  if (p->M % 1024 || p->K % 64 || p->M <= 0 || p->N <= 0 || p->K <= 0) return 3;   // 8 XCDs x whole row blocks
+  const int tile = p->N % 384 == 0 ? 384 : p->N % 256 == 0 ? 256 : 0;
+  if (!tile || p->N / tile > 4) return 3;
+  if (!p->ln_gamma || !p->ln_mean || !p->ln_rstd || !p->ln_xchg || !p->ln_err || !p->C) return 1;
+  if (mode == 5 && (!p->ln_beta || !p->C2)) return 1;
+  if (mode == 6 && (!p->aux || !p->colpart)) return 1;
+  dim3 grid((p->M / 128) * (p->N / tile)), block(512);
+  const double mnk = (double)p->M * p->N * p->K;
+  const double bytes = 2.0 * ((double)p->M * p->K + (double)p->N * p->K) + (double)p->M * p->N * (mode == 5 ? 4 : 4) +
+                       (p->res ? 2.0 * p->M * p->N : 0.0);
+  const int tok = plb_prof_begin(mode == 5 ? PLB_K_GEMM_NT_LNFWD : PLB_K_GEMM_NT_LNBWD, stream, 2.0 * mnk, bytes);
+  if (tile == 384) {
+    if (mode == 5) hipLaunchKernelGGL((gemm_nt_big_kernel<3, 5, false, true>), grid, block, 0, stream, *p);
+    else hipLaunchKernelGGL((gemm_nt_big_kernel<3, 6, false, true>), grid, block, 0, stream, *p);
+  } else {
+    if (mode == 5) hipLaunchKernelGGL((gemm_nt_big_kernel<1, 5, false, true>), grid, block, 0, stream, *p);
+    else hipLaunchKernelGGL((gemm_nt_big_kernel<1, 6, false, true>), grid, block, 0, stream, *p);
+  }
+  plb_prof_end(tok, stream);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}

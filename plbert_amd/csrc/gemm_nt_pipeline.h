@@ -67,8 +67,17 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = uw >> 2, wn = uw & 3;
   const int nbn = p.N / TN;
-  const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int bm = logical / nbn, bn = logical % nbn;
+  int bm, bn;
+  if constexpr (ACT >= 5) {
+    // LayerNorm forms: the nbn column tiles of a row block exchange row partials inside the launch, so they sit on
+    // consecutive dispatch slots of ONE XCD (block ids b, b + 8, ...: placement is a speed / latency matter only, the
+    // hand-off is agent-scope). (M / 128) % 8 == 0 is checked by the launcher.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, gpx = (p.M / TM) >> 3;
+    bm = xcd * gpx + slot / nbn; bn = slot % nbn;
+  } else {
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    bm = logical / nbn; bn = logical % nbn;
+  }
   constexpr int EPK = FP8 ? 128 : 64;  // elements of k per 128-byte K-tile row
   const int nk = p.K / EPK;
 #if NT_DBG & 16
@@ -161,6 +170,22 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       for (int c = 0; c < NBH; ++c)
 #pragma unroll
         for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (ACT == 6) {
+    // LayerNorm-backward form: the residual is the accumulators' START value (its segments arrive under the prologue's
+    // DMA), not an epilogue operand — beside the kept pre segments it would not fit the epilogue's registers
+    if (p.res) {
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) {
+            const uint2 r = *(const uint2*)(p.res + (size_t)(bm * TM + wm * 64 + mi * 16 + frow) * p.ldr + bn * TN + wn * 32 +
+                                            fq * 4 + nh * 128 + ni * 16);
+            acc[0][mi][nh][ni] = f32x4{bf_lo(r.x), bf_hi(r.x), bf_lo(r.y), bf_hi(r.y)};
+          }
+    }
+  }
   // swapped MFMA operands: D[row = n][col = m] -> each lane owns 4 consecutive n of one row m
 #define MFMA_Q(mh, nh, ab, bb)                                                                                 \
   do {                                                                                                         \
@@ -490,6 +515,222 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       }
       p.ce_pmax[(size_t)(bm * TM + r) * ntile + bn] = mx;
       p.ce_psum[(size_t)(bm * TM + r) * ntile + bn] = sm;
+    }
+    return;
+  }
+  if constexpr (ACT == 5 || ACT == 6) {
+    // ---- LayerNorm in the epilogue. A row of the normalised matrix spans the nbn column tiles of its row block: each
+    // tile forms its rows' partial statistics over its TN columns, publishes them to its partners as tagged 8-byte
+    // granules (guide: "the data IS the flag"), collects its partners' and finishes its own columns. A granule is written
+    // by its producer and cleared by its one consumer, so the exchange buffer is all zero again when the launch ends (no
+    // per-launch memset, no epoch argument: the launch can be captured in a graph). The wait is bounded: a time-out
+    // raises *ln_err instead of hanging the device.
+    static_assert(NAH == 1, "LayerNorm epilogues: 128-row tiles");
+    constexpr int IMG = TM * OROW * 2;                          // bytes of the output image
+    float* const tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + IMG);   // [128 rows][4 wn][2]
+    float* const tab2 = tab + 128 * 4 * 2;                                                // [128 rows][2] merged
+    typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+    gu64_t* const xq = (gu64_t*)(p.ln_xchg);
+    const float invN = 1.0f / (float)p.N;
+    // per-tile row partials (a, b): forward a = sum x, b = sum x^2 ; backward a = sum dy*gamma, b = sum dy*gamma*xhat
+    // every residual / pre segment of the tile is requested up front: in MFMA layout a load instruction touches 16 rows x
+    // 32 B, and one dependent round trip per 16-row slab (the plain epilogue's form) cost this epilogue ~10 us per launch
+    float rmean[4], rrstd[4];
+    uint2 rr[4][NBH][2], ux[4][NBH][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int m = bm * TM + wm * 64 + mi * 16 + frow;
+#pragma unroll
+      for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          if constexpr (ACT == 5) { if (p.res) rr[mi][nh][ni] = *(const uint2*)(p.res + (size_t)m * p.ldr + ncol0 + nh * 128 + ni * 16); }
+          if constexpr (ACT == 6) ux[mi][nh][ni] = *(const uint2*)(p.aux + (size_t)m * p.ldaux + ncol0 + nh * 128 + ni * 16);
+        }
+      if constexpr (ACT == 6) { rmean[mi] = p.ln_mean[m]; rrstd[mi] = p.ln_rstd[m]; }
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const float4 gz = *(const float4*)(p.ln_gamma + ncol0 + nh * 128 + ni * 16);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int lrow = wm * 64 + mi * 16 + frow;
+          f32x4 v = acc[0][mi][nh][ni];
+          if constexpr (ACT == 5) { v[0] += bz[nh][ni].x; v[1] += bz[nh][ni].y; v[2] += bz[nh][ni].z; v[3] += bz[nh][ni].w; }
+          if constexpr (ACT == 5) {
+            if (p.res) {
+              v[0] += bf_lo(rr[mi][nh][ni].x); v[1] += bf_hi(rr[mi][nh][ni].x);
+              v[2] += bf_lo(rr[mi][nh][ni].y); v[3] += bf_hi(rr[mi][nh][ni].y);
+            }
+          }
+          // the value as a bf16 store would leave it: what the separate LayerNorm kernels read
+          uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
+          v = f32x4{bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};
+          if constexpr (ACT == 5) {
+            *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = o;   // image 1: pre
+            s1[mi] += (v[0] + v[1]) + (v[2] + v[3]);
+            s2[mi] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+          } else {
+            const uint2 u = ux[mi][nh][ni];
+            const f32x4 xh = {(bf_lo(u.x) - rmean[mi]) * rrstd[mi], (bf_hi(u.x) - rmean[mi]) * rrstd[mi],
+                              (bf_lo(u.y) - rmean[mi]) * rrstd[mi], (bf_hi(u.y) - rmean[mi]) * rrstd[mi]};
+            const f32x4 g = {v[0] * gz.x, v[1] * gz.y, v[2] * gz.z, v[3] * gz.w};
+            s1[mi] += (g[0] + g[1]) + (g[2] + g[3]);
+            s2[mi] += (g[0] * xh[0] + g[1] * xh[1]) + (g[2] * xh[2] + g[3] * xh[3]);
+          }
+          acc[0][mi][nh][ni] = v;   // forward: x; backward: dy (the second pass forms dy*gamma again)
+        }
+      }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int lrow = wm * 64 + mi * 16 + frow;
+      float a1 = s1[mi], a2 = s2[mi];
+      a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+      a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+      if (fq == 0) { tab[(lrow * 4 + wn) * 2] = a1; tab[(lrow * 4 + wn) * 2 + 1] = a2; }
+    }
+    __syncthreads();
+    float pa = 0.f, pb = 0.f;   // this tile's partial of row tid (threads 0..127)
+    if (tid < TM) {
+      pa = (tab[(tid * 4 + 0) * 2] + tab[(tid * 4 + 1) * 2]) + (tab[(tid * 4 + 2) * 2] + tab[(tid * 4 + 3) * 2]);
+      pb = (tab[(tid * 4 + 0) * 2 + 1] + tab[(tid * 4 + 1) * 2 + 1]) + (tab[(tid * 4 + 2) * 2 + 1] + tab[(tid * 4 + 3) * 2 + 1]);
+      if constexpr (ACT == 5) {   // (mean, M2) of the tile's TN values: merged below without cancellation
+        const float mt = pa * (1.0f / (float)TN);
+        pb = pb - pa * mt;
+        pa = mt;
+      }
+      // publish: the data IS the flag — one naturally aligned 8-byte granule {value, tag = 1} per number and consumer,
+      // written by ONE agent-scope store each (no flag word, no fence, no drain: a granule is either old or whole)
+      const unsigned long long wa = (1ull << 32) | __float_as_uint(pa), wb = (1ull << 32) | __float_as_uint(pb);
+      for (int c = 0; c < nbn; ++c)
+        if (c != bn) {
+          gu64_t* g = xq + (((size_t)(bm * nbn + bn) * nbn + c) * TM + tid) * 2;
+          __hip_atomic_store(g, wa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(g + 1, wb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if constexpr (ACT == 5) {   // image 1 (pre) leaves while the partners' partials arrive
+      constexpr int CPR = TN / 8;
+      bf16_t* const cbase = p.C + (size_t)(bm * TM) * p.ldc + bn * TN;
+      const int rows_ok = p.Mstore - bm * TM;
+#pragma unroll 4
+      for (int c = tid; c < TM * CPR; c += 512) {
+        const int r = c / CPR, cc = c - r * CPR;
+        const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
+        if (r < rows_ok) *(uint4*)(cbase + (size_t)r * p.ldc + cc * 8) = v;
+      }
+    }
+    if (tid < TM) {   // collect and merge the nbn partials of row tid in tile order (the same arithmetic on every tile)
+      float qa[4], qb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        qa[j] = 0.f; qb[j] = 0.f;
+        if (j < nbn) {
+          if (j == bn) { qa[j] = pa; qb[j] = pb; }
+          else {
+            // consume: re-read this row's two granules of producer j (agent-scope loads: past the L1) until both carry
+            // the tag, then clear them — every granule has one writer and one clearer, so the buffer is all zero
+            // again when the launch ends (no memset, no epoch argument; the wait is bounded)
+            gu64_t* g = xq + (((size_t)(bm * nbn + j) * nbn + bn) * TM + tid) * 2;
+            unsigned long long wa = 0, wb = 0;
+            bool seen = false;
+            for (unsigned spins = 0; spins < (1u << 21); ++spins) {   // ~0.1 s: far beyond any launch
+              wa = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              wb = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((wa >> 32) == 1ull && (wb >> 32) == 1ull) { seen = true; break; }
+              __builtin_amdgcn_s_sleep(4);
+            }
+            if (!seen) atomicAdd(p.ln_err, 1u);
+            __hip_atomic_store(g, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            qa[j] = __uint_as_float((unsigned int)wa); qb[j] = __uint_as_float((unsigned int)wb);
+          }
+        }
+      }
+      if constexpr (ACT == 5) {
+        float mean = 0.f;
+        for (int j = 0; j < nbn; ++j) mean += qa[j];
+        mean *= 1.0f / (float)nbn;
+        float m2 = 0.f;
+        for (int j = 0; j < nbn; ++j) m2 += qb[j] + (float)TN * (qa[j] - mean) * (qa[j] - mean);
+        const float rstd = rsqrtf(m2 * invN + p.ln_eps);
+        tab2[tid * 2] = mean; tab2[tid * 2 + 1] = rstd;
+        const int m = bm * TM + tid;
+        if (bn == 0 && m < p.Mstore) { p.ln_mean[m] = mean; p.ln_rstd[m] = rstd; }
+      } else {
+        float a = 0.f, b = 0.f;
+        for (int j = 0; j < nbn; ++j) { a += qa[j]; b += qb[j]; }
+        tab2[tid * 2] = a * invN; tab2[tid * 2 + 1] = b * invN;
+      }
+    }
+    __syncthreads();   // also: every thread's reads of image 1 have retired (its stores consumed them)
+    // second pass, one 4-column group of the lane at a time (its 4 rows innermost): the three column sums of the backward
+    // then need 12 registers instead of 72, which is what lets the pre segments of the first pass stay in registers
+    float t0[4], t1[4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) { t0[mi] = tab2[(wm * 64 + mi * 16 + frow) * 2]; t1[mi] = tab2[(wm * 64 + mi * 16 + frow) * 2 + 1]; }
+#pragma unroll
+    for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        float4 bt = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gz = *(const float4*)(p.ln_gamma + ncol0 + nh * 128 + ni * 16);
+        if constexpr (ACT == 5) bt = *(const float4*)(p.ln_beta + ncol0 + nh * 128 + ni * 16);
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const int lrow = wm * 64 + mi * 16 + frow;
+          const f32x4 x = acc[0][mi][nh][ni];
+          f32x4 y;
+          if constexpr (ACT == 5) {
+            y = f32x4{(x[0] - t0[mi]) * t1[mi] * gz.x + bt.x, (x[1] - t0[mi]) * t1[mi] * gz.y + bt.y,
+                      (x[2] - t0[mi]) * t1[mi] * gz.z + bt.z, (x[3] - t0[mi]) * t1[mi] * gz.w + bt.w};
+          } else {
+            const float mu = rmean[mi], rs = rrstd[mi];
+            uint2 u = ux[mi][nh][ni];
+            // opaque copy: otherwise hipcc keeps the first pass's 96 unpacked xhat values alive across the hand-off
+            // (common sub-expressions of the two passes) instead of the 48 packed registers, and spills
+            asm volatile("" : "+v"(u.x), "+v"(u.y));
+            const f32x4 xh = {(bf_lo(u.x) - mu) * rs, (bf_hi(u.x) - mu) * rs, (bf_lo(u.y) - mu) * rs, (bf_hi(u.y) - mu) * rs};
+            dg += x * xh; db += x;
+            y = f32x4{rs * (x[0] * gz.x - t0[mi] - xh[0] * t1[mi]), rs * (x[1] * gz.y - t0[mi] - xh[1] * t1[mi]),
+                      rs * (x[2] * gz.z - t0[mi] - xh[2] * t1[mi]), rs * (x[3] * gz.w - t0[mi] - xh[3] * t1[mi])};
+          }
+          uint2 o; o.x = pack_bf2(y[0], y[1]); o.y = pack_bf2(y[2], y[3]);
+          *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = o;
+          if (ACT == 6 && bm * TM + lrow < p.Mstore) cs += f32x4{bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};
+        }
+        if constexpr (ACT == 6) {
+          // dgamma | dbeta | column sums of dx over this wave's 64 rows: one partial row per (row tile, wm)
+#pragma unroll
+          for (int q3 = 0; q3 < 3; ++q3) {
+            f32x4 v = q3 == 0 ? dg : q3 == 1 ? db : cs;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+              v[0] += __shfl_xor(v[0], o, 64); v[1] += __shfl_xor(v[1], o, 64);
+              v[2] += __shfl_xor(v[2], o, 64); v[3] += __shfl_xor(v[3], o, 64);
+            }
+            if (frow == 0)
+              *(float4*)(p.colpart + ((size_t)(bm * 2 + wm) * 3 + q3) * p.N + bn * TN + nh * 128 + wn * 32 + ni * 16 + fq * 4) =
+                  make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    __syncthreads();
+    {
+      constexpr int CPR = TN / 8;
+      bf16_t* const obase = (ACT == 5 ? p.C2 + (size_t)(bm * TM) * p.ldc2 : p.C + (size_t)(bm * TM) * p.ldc) + bn * TN;
+      const int ldo = ACT == 5 ? p.ldc2 : p.ldc;
+      const int rows_ok = p.Mstore - bm * TM;
+#pragma unroll 4
+      for (int c = tid; c < TM * CPR; c += 512) {
+        const int r = c / CPR, cc = c - r * CPR;
+        const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
+        if (r < rows_ok) *(uint4*)(obase + (size_t)r * ldo + cc * 8) = v;
+      }
     }
     return;
   }

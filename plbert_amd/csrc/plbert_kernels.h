@@ -14,6 +14,7 @@ enum PlbKernelClass {
   PLB_K_ATTN_FWD, PLB_K_ATTN_BWD_DQ, PLB_K_ATTN_BWD_DKV, PLB_K_LN_FWD, PLB_K_LN_BWD, PLB_K_EMBED_FWD,
   PLB_K_EMBED_BWD, PLB_K_COLSUM, PLB_K_REDUCE, PLB_K_ROWS, PLB_K_CE, PLB_K_ADAMW, PLB_K_CAST, PLB_K_TOKEN_CE, PLB_K_GEMM_NT_CE, PLB_K_GEMM_NT_SMALL, PLB_K_FP8, PLB_K_ATTN_BWD,
   PLB_K_GEMM_NT_FP8, PLB_K_GEMM_NT_GELU_FP8, PLB_K_GEMM_NT_GELUBWD_FP8,  // the fp8 launches: priced against the fp8 MFMA peak
+  PLB_K_GEMM_NT_LNFWD, PLB_K_GEMM_NT_LNBWD,  // GEMM + LayerNorm epilogue (gemm_ln.hip)
   PLB_K_NCLASS
 };
 int plb_prof_begin(int cls, hipStream_t s, double flops, double bytes);
@@ -45,7 +46,23 @@ typedef struct {
   const float* q_scale;         // device scalar: C8 = saturate(value * q_scale[0])
   float* q_amax;                // device scalar: atomic max of |value| over the launch (next step's scale)
   int c8_bf8;                   // C8 format: 0 e4m3, 1 e5m2
+  // LayerNorm fused into the epilogue (plb_launch_gemm_nt_ln, gemm_ln.hip; N = the normalised width, a row spans the
+  // N / TN column tiles of its row block, which exchange their row partials in global memory inside the launch):
+  const float* ln_gamma; const float* ln_beta;  // [N]
+  float* ln_mean; float* ln_rstd;               // [M]: written by the forward form, read by the backward form
+  float ln_eps;
+  unsigned long long* ln_xchg;  // [(M/128)][N/TN producer][N/TN consumer][128 rows][2] tagged granules; zero before and after every launch
+  unsigned int* ln_err;         // incremented when a hand-off timed out (results of that launch are then invalid)
 } PlbGemmNT;
+// LayerNorm in the epilogue of the GEMM that produces its input (big-tile kernels with 128-row tiles; M % 1024 == 0,
+// N % 384 == 0 or N % 256 == 0):
+//  mode 5, forward:  C = bf16(A·B^T + bias + res) ("pre", kept for the backward), C2 = LayerNorm(C)·gamma + beta,
+//                    ln_mean / ln_rstd written
+//  mode 6, backward: dy = bf16(A·B^T + res) is the gradient of the LayerNorm's OUTPUT and is never stored; aux = the
+//                    forward's pre, ln_mean / ln_rstd read; C = the gradient of the LayerNorm's input;
+//                    colpart[2*M/128][3][N] = per (row tile, wave half) dgamma | dbeta | column sums of C
+// Returns 3 when the shape has no fused form (the caller runs the GEMM and the LayerNorm kernel separately).
+int plb_launch_gemm_nt_ln(const PlbGemmNT* p, int mode, hipStream_t stream);
 // fp8 (e4m3 weights; e4m3 or e5m2 activations / gradients) form of plb_launch_gemm_nt on the pipeline kernel.
 // Returns 3 when the shape has no big-tile form (the caller then uses the bf16 GEMM).
 int plb_launch_gemm_nt_fp8(const PlbGemmNT* p, int act, int a_bf8, hipStream_t stream);

@@ -179,6 +179,13 @@ class HipEngine:
         _lib.check(self.L.plb_comm_info(self.handle, C.byref(r), C.byref(w), C.byref(v)), "plb_comm_info")
         return int(r.value), int(w.value), int(v.value)
 
+    def status(self):
+        """{'ln_exchange_timeouts': n} — synchronises the device (plb_status)."""
+        n = C.c_int32()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.plb_status(self.handle, C.byref(n)), "plb_status")
+        return {"ln_exchange_timeouts": int(n.value)}
+
     def comm_pieces(self):
         """(collectives, floats) of the last step's gradient exchange."""
         n, f = C.c_int32(), C.c_int64()

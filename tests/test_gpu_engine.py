@@ -365,6 +365,7 @@ def _size_independent_properties(pcfg, B, S, fp8=False, tol_lin=2e-2, tol_perm=1
     l3, g3 = run(perm)
     assert abs(l3 - l1) / l1 < (2e-2 if fp8 else 2e-5)
     assert rel_l2(g3.cpu(), g1.cpu()) < tol_perm                               # (3) order of summation only
+    assert eng.status()["ln_exchange_timeouts"] == 0                          # every in-launch hand-off of the LayerNorm epilogues arrived
     return eng
 
 
@@ -387,3 +388,32 @@ def test_full_size_properties_fp8():
     pcfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
                                    max_position_embeddings=512, num_hidden_layers=12)
     _size_independent_properties(pcfg, 32, 512, fp8=True, tol_lin=0.25, tol_perm=0.25)
+
+
+def test_layernorm_in_gemm_epilogue_matches_separate_kernels(monkeypatch):
+    """The dense / FFN-output GEMMs carry their LayerNorm (forward) and the dX GEMMs the backward of the LayerNorm whose
+    output gradient they produce (csrc/gemm_ln.hip; needs 1024-row multiples). Same step with PLBERT_LN_FUSE=off: the
+    stored pre-LayerNorm sums are bit-identical by construction, the statistics are merged from per-tile partials instead
+    of one two-pass sweep, so everything downstream agrees to bf16 rounding; both sit inside the reference tolerances
+    (tests above run the fused path against the reference-captured fixture real_s512_b2_ragged: T = 1024)."""
+    pcfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                                   max_position_embeddings=512, num_hidden_layers=12)
+    sd = plbert_amd.deterministic_state_dict(pcfg, 188, seed=3)
+    labels, masked, lengths, idx = plbert_amd.synthetic_batch(4, 512, seed=99)
+    off, flat = plbert_amd.masked_indices_to_csr(idx)
+    out = {}
+    for mode in ("off", "both"):
+        monkeypatch.setenv("PLBERT_LN_FUSE", mode)
+        eng = HipEngine(pcfg, 188, 0, max_batch=4, max_seq=512)
+        eng.load_state_dict(sd)
+        loss = eng.loss_fwd_bwd(masked, labels, None, off, flat, int(off[-1]))
+        torch.cuda.synchronize()
+        assert eng.status()["ln_exchange_timeouts"] == 0
+        out[mode] = (float(loss.item()), eng.grads[: eng.trainable].clone().cpu(), dict(eng.layout), eng.trainable)
+        del eng
+    (l0, g0, layout, ntrain), (l1, g1, _, _) = out["off"], out["both"]
+    assert abs(l0 - l1) / l0 < 2e-4
+    assert rel_l2(g1, g0) < 1.5e-2
+    for name, (o, n, shp) in layout.items():                                   # and tensor by tensor (LayerNorm affine, biases too)
+        if o + n <= ntrain and float(g0[o:o + n].norm()) > 1e-6 and "key.bias" not in name:
+            assert rel_l2(g1[o:o + n], g0[o:o + n]) < 3e-2, name

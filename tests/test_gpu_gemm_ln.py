@@ -1,0 +1,138 @@
+"""GEMM with LayerNorm in the epilogue (-m gpu; csrc/gemm_ln.hip, gemm_nt_pipeline.h ACT 5 / 6): the dense / FFN-output
+projections + AlbertAttention.LayerNorm / full_layer_layer_norm forward (modeling_albert.py:196-200, 225-238) and the
+backward of those LayerNorms inside the dX GEMM that produces their output gradient. The column tiles of a row block
+exchange row partials INSIDE the launch (agent-scope hand-off): besides the arithmetic (against fp32 torch on the same
+bf16 operands, and bit for bit against the unfused GEMM for the stored pre-LayerNorm sums) the tests check the hand-off:
+flags back to zero, no time-out, repeated launches bitwise identical with the consumers' caches warm."""
+import ctypes as C
+
+import pytest
+import torch
+
+from gpu_util import gemm_nt, rel_l2, stream
+from plbert_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def randbf(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
+
+
+class Ln:
+    """Buffers of one fused launch."""
+
+    def __init__(self, M, N, K, seed=0):
+        self.M, self.N, self.K = M, N, K
+        self.A, self.B = randbf(M, K, seed=seed + 1), randbf(N, K, scale=K ** -0.5, seed=seed + 2)
+        self.bias = torch.randn(N, generator=torch.Generator().manual_seed(seed + 3)).to(DEV)
+        self.res = randbf(M, N, seed=seed + 4)
+        g = torch.Generator().manual_seed(seed + 5)
+        self.gamma = (1.0 + 0.3 * torch.randn(N, generator=g)).to(DEV)
+        self.beta = (0.2 * torch.randn(N, generator=g)).to(DEV)
+        nbn = N // (384 if N % 384 == 0 else 256)
+        self.nbn = nbn
+        self.xchg = torch.zeros(M // 128 * nbn * nbn * 128 * 2, dtype=torch.int64, device=DEV)
+        self.err = torch.zeros(1, dtype=torch.int32, device=DEV)
+        self.mean = torch.zeros(M, dtype=torch.float32, device=DEV)
+        self.rstd = torch.zeros(M, dtype=torch.float32, device=DEV)
+
+    def params(self):
+        p = _lib.PlbGemmNT()
+        p.A, p.lda, p.B, p.ldb = self.A.data_ptr(), self.K, self.B.data_ptr(), self.K
+        p.M, p.N, p.K, p.Mstore = self.M, self.N, self.K, self.M
+        p.ln_gamma, p.ln_beta, p.ln_mean, p.ln_rstd = self.gamma.data_ptr(), self.beta.data_ptr(), self.mean.data_ptr(), self.rstd.data_ptr()
+        p.ln_eps = 1e-12
+        p.ln_xchg, p.ln_err = self.xchg.data_ptr(), self.err.data_ptr()
+        return p
+
+
+def _fwd(t, reps=1):
+    L = _lib.lib()
+    pre = torch.zeros(t.M, t.N, dtype=torch.bfloat16, device=DEV)
+    y = torch.zeros_like(pre)
+    p = t.params()
+    p.bias, p.res, p.ldr = t.bias.data_ptr(), t.res.data_ptr(), t.N
+    p.C, p.ldc, p.C2, p.ldc2 = pre.data_ptr(), t.N, y.data_ptr(), t.N
+    outs = []
+    for _ in range(reps):
+        assert L.plb_launch_gemm_nt_ln(C.byref(p), 5, stream()) == 0
+        torch.cuda.synchronize()
+        outs.append((pre.clone(), y.clone(), t.mean.clone(), t.rstd.clone()))
+    return outs
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (2048, 768, 2048), (1024, 1024, 1024), (16384, 768, 768)])
+def test_gemm_layernorm_forward(M, N, K):
+    t = Ln(M, N, K, seed=M + N)
+    pre, y, mean, rstd = _fwd(t)[0]
+    ref_pre, _ = gemm_nt(t.A, t.B, N, bias=t.bias, res=t.res)
+    assert torch.equal(pre, ref_pre)                                        # the stored sum is the unfused GEMM's, bit for bit
+    x = pre.float()
+    mu, var = x.mean(1), x.var(1, unbiased=False)
+    assert (mean - mu).abs().max() < 1e-5 * max(1.0, float(mu.abs().max()))
+    assert ((rstd - (var + 1e-12).rsqrt()) / rstd).abs().max() < 1e-5
+    ref_y = torch.nn.functional.layer_norm(x, (N,), t.gamma, t.beta, 1e-12)
+    assert rel_l2(y.float(), ref_y) < 3e-3
+    assert int(t.err.item()) == 0 and int(t.xchg.abs().sum().item()) == 0  # no time-out; every hand-off word cleared
+
+
+def _bwd(t, reps=1):
+    """dy = bf16(A·B^T + res) is the gradient of the LayerNorm output; aux = pre of a forward over other operands."""
+    L = _lib.lib()
+    pre = randbf(t.M, t.N, seed=77)
+    x = pre.float()
+    t.mean.copy_(x.mean(1)); t.rstd.copy_((x.var(1, unbiased=False) + 1e-12).rsqrt())
+    dx = torch.zeros(t.M, t.N, dtype=torch.bfloat16, device=DEV)
+    colp = torch.full((2 * t.M // 128, 3, t.N), 9.0, dtype=torch.float32, device=DEV)
+    p = t.params()
+    p.res, p.ldr, p.aux, p.ldaux = t.res.data_ptr(), t.N, pre.data_ptr(), t.N
+    p.C, p.ldc, p.colpart = dx.data_ptr(), t.N, colp.data_ptr()
+    outs = []
+    for _ in range(reps):
+        assert L.plb_launch_gemm_nt_ln(C.byref(p), 6, stream()) == 0
+        torch.cuda.synchronize()
+        outs.append((dx.clone(), colp.clone()))
+    return pre, outs
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 2048), (2048, 768, 2304), (1024, 1024, 4096), (16384, 768, 2048)])
+def test_gemm_layernorm_backward(M, N, K):
+    t = Ln(M, N, K, seed=M + K)
+    pre, outs = _bwd(t)
+    dx, colp = outs[0]
+    dy, _ = gemm_nt(t.A, t.B, N, res=t.res)                                  # what the unfused path stores and reads back
+    x = pre.float().requires_grad_(True)
+    gamma = t.gamma.clone().requires_grad_(True)
+    beta = t.beta.clone().requires_grad_(True)
+    yy = torch.nn.functional.layer_norm(x, (N,), gamma, beta, 1e-12)
+    yy.backward(dy.float())
+    assert rel_l2(dx.float(), x.grad) < 4e-3
+    sums = colp.double().sum(0)
+    assert rel_l2(sums[0], gamma.grad.double()) < 1e-4                       # dgamma
+    assert rel_l2(sums[1], beta.grad.double()) < 1e-4                        # dbeta
+    assert rel_l2(sums[2], dx.double().sum(0)) < 1e-5                        # column sums of dx as stored (bias gradient)
+    assert int(t.err.item()) == 0 and int(t.xchg.abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("mode", [5, 6])
+def test_hand_off_race_screen(mode):
+    """The partner tiles' partials cross CUs (possibly XCDs) inside the launch: 60 launches over the SAME buffers — the
+    consumers' caches hold the previous launch's lines — must agree bit for bit, at a shape with 2 and one with 4 column
+    tiles per row block."""
+    for (M, N, K) in ((4096, 768, 768), (2048, 1024, 1024)):
+        t = Ln(M, N, K, seed=5)
+        outs = _fwd(t, reps=60) if mode == 5 else _bwd(t, reps=60)[1]
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
+        assert int(t.err.item()) == 0 and int(t.xchg.abs().sum().item()) == 0
+
+
+def test_unsupported_shapes_are_refused():
+    L = _lib.lib()
+    t = Ln(1024, 768, 768)
+    p = t.params()
+    p.M = 896                                                                # not a multiple of 1024: no fused form
+    assert L.plb_launch_gemm_nt_ln(C.byref(p), 5, stream()) == 3

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 P=plbert_amd
 O=$P/build/ab/$1
 mkdir -p $O
-for f in gemm.hip gemm_big.hip gemm_fp8.hip attn.hip attn_bwd_fused.hip rowops.hip mask.hip engine.cpp; do
+for f in gemm.hip gemm_big.hip gemm_fp8.hip gemm_ln.hip attn.hip attn_bwd_fused.hip rowops.hip mask.hip engine.cpp; do
   X=""; [ "$f" == "attn_bwd_fused.hip" ] && X="-mllvm -amdgpu-mfma-vgpr-form=1"   # plbert_amd/build.py: EXTRA_FLAGS
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC $X "${@:2}" -x hip -c $P/csrc/$f -o $O/${f%.*}.o &
 done
