@@ -228,6 +228,8 @@ def lib():
     L.plb_launch_attn_fwd.argtypes = [C.POINTER(PlbAttn), vp]
     L.plb_launch_gemm_nt_ln.restype = C.c_int
     L.plb_launch_gemm_nt_ln.argtypes = [C.POINTER(PlbGemmNT), C.c_int, vp]
+    L.plb_launch_gemm_nt_gelud.restype = C.c_int
+    L.plb_launch_gemm_nt_gelud.argtypes = [C.POINTER(PlbGemmNT), C.c_int, vp]
     L.plb_launch_attn_bwd.restype = C.c_int
     L.plb_launch_attn_bwd.argtypes = [C.POINTER(PlbAttn), vp]
     L.plb_launch_attn_bwd_fused.restype = C.c_int

@@ -180,6 +180,8 @@ struct PlbEngine {
   int part_rows_used = 0;       // rows per layer the last backward wrote
   int ln_fuse = 3;              // bit 0: LayerNorm forward in the producing GEMM's epilogue, bit 1: LayerNorm backward
   int64_t o_lnx = 0, o_lnerr = 0;
+  bool gelu_dstash_on = true;   // PLBERT_GELU_STASH=u restores the pre-activation stash
+  bool u_is_derivative = false; // what the "u" slots hold after the last forward
   // fp8 mode (plb_set_fp8): transient 1-byte images of the fp8 GEMMs' activation / gradient operands, fp8 weight copies
   // and the per-(site, layer) delayed-scaling state [amax | scale | deq] (+ one entry per weight copy)
   bool fp8_on = false, fp8_ready = false, fp8_bwd_ready = false, fp8_wstale = true;
@@ -305,6 +307,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   if (const char* v = getenv("PLBERT_LN_FUSE"))
     e->ln_fuse = !strcmp(v, "off") ? 0 : !strcmp(v, "fwd") ? 1 : !strcmp(v, "bwd") ? 2 : 3;
   e->part_rows = e->ln_blocks > (int)(2 * Tp / 128) ? e->ln_blocks : (int)(2 * Tp / 128);
+  if (const char* v = getenv("PLBERT_GELU_STASH")) e->gelu_dstash_on = strcmp(v, "u") != 0;
   Carve cv;
   // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes
   e->o_wbf = cv.take((e->ptotal + 256 * (H > I ? H : I)) * 2);
@@ -603,6 +606,12 @@ static bool ln_fusable(const PlbEngine* e, int64_t Tp, int bit, bool f8_call) {
   const int H = e->H;
   return (e->ln_fuse & bit) && !f8_call && Tp % 1024 == 0 && (H % 384 == 0 ? H / 384 : H % 256 == 0 ? H / 256 : 99) <= 4;
 }
+// Does the forward of this call stash gelu_new'(u) instead of u (plb_launch_gemm_nt_gelud)? Recorded in the engine: the
+// backward of the same call must read the stash the way the forward wrote it.
+static bool gelu_dstash(PlbEngine* e, int64_t Tp, bool f8_call) {
+  e->u_is_derivative = e->gelu_dstash_on && !f8_call && Tp % 256 == 0 && e->I % 256 == 0;  // (an fp8 calibration call computes in bf16)
+  return e->u_is_derivative;
+}
 static void ln_fields(const PlbEngine* e, PlbGemmNT* g, const float* gamma, const float* beta, float* mean, float* rstd) {
   g->ln_gamma = gamma; g->ln_beta = beta; g->ln_mean = mean; g->ln_rstd = rstd; g->ln_eps = e->c.layer_norm_eps;
   g->ln_xchg = e->at<unsigned long long>(e->o_lnx); g->ln_err = e->at<unsigned int>(e->o_lnerr);
@@ -694,7 +703,10 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     g.bias = e->par(PLB_FFN_B); g.C = u; g.ldc = I; g.C2 = gl; g.ldc2 = I;
     if (f8) { g.C8 = g8; g.ldc8 = I; g.q_scale = f8_scale(e, sG); g.q_amax = f8_amax(e, sG); g.c8_bf8 = 0; }
     F8Op o1 = {a8, e->at<uint8_t>(e->o_w18), f8_deq(e, sA), f8_deq(e, f8_w(e, F8W_1)), 0};
-    TRY(gemm_nt_any(&g, 1, f8 ? &o1 : nullptr, s));
+    // bf16 calls on 256-multiples stash gelu_new'(u) in the "u" slot (gelu_dstash): the forward's sigmoid serves the
+    // activation and its derivative, and the backward epilogue multiplies instead of evaluating the derivative
+    if (gelu_dstash(e, Tp, f8)) TRY(plb_launch_gemm_nt_gelud(&g, 0, s));
+    else TRY(gemm_nt_any(&g, 1, f8 ? &o1 : nullptr, s));
     if (calib) TRY(plb_launch_amax(gl, 1, (size_t)T, I, I, f8_amax(e, sG), s));
     memset(&g, 0, sizeof(g));
     g.A = gl; g.lda = I; g.B = e->wbf(PLB_FFNO_W); g.ldb = I; g.M = (int)Tp; g.N = H; g.K = I; g.Mstore = (int)Tp;
@@ -972,7 +984,7 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
   const bool f8 = e->fp8_on && e->fp8_bwd_ready && fp8_shapes_ok(e, Tp);
   const bool calib = e->fp8_on && !e->fp8_bwd_ready;
   // ffn.bias gradient from the dU GEMM's epilogue: 2 partial rows per row tile of the kernel that runs it
-  const int du_rows = f8 ? 2 * (int)(Tp / 128) : plb_gemm_nt_colpart_rows((int)Tp, I, H);
+  const int du_rows = f8 ? 2 * (int)(Tp / 128) : e->u_is_derivative ? 2 * (int)(Tp / 256) : plb_gemm_nt_colpart_rows((int)Tp, I, H);
   bf16_t* da = e->at<bf16_t>(e->o_da);
   bf16_t* dctx = e->at<bf16_t>(e->o_dctx);
   uint8_t* dp8 = e->at<uint8_t>(e->o_dp8);
@@ -1012,7 +1024,8 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     if (du_rows > 0) g.colpart = e->at<float>(e->o_ducol) + (int64_t)l * du_rows * I;
     if (f8) { g.C8 = du8; g.ldc8 = I; g.q_scale = f8_scale(e, sDU); g.q_amax = f8_amax(e, sDU); g.c8_bf8 = 1; }
     F8Op ou = {dp8, e->at<uint8_t>(e->o_w2T8), f8_deq(e, sDP), f8_deq(e, f8_w(e, F8W_2T)), 1};
-    TRY(gemm_nt_any(&g, 2, f8 ? &ou : nullptr, s));
+    if (e->u_is_derivative) TRY(plb_launch_gemm_nt_gelud(&g, 1, s));   // what the forward of THIS call stashed
+    else TRY(gemm_nt_any(&g, 2, f8 ? &ou : nullptr, s));
     if (calib) TRY(plb_launch_amax(du, 1, (size_t)T, I, I, f8_amax(e, sDU), s));
     // dA = dU · W1 + dpre2
     memset(&g, 0, sizeof(g));

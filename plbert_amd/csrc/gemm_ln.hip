@@ -27,3 +27,20 @@ extern "C" int plb_launch_gemm_nt_ln(const PlbGemmNT* p, int mode, hipStream_t s
   plb_prof_end(tok, stream);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
+
+// gelu_new epilogues that stash the DERIVATIVE (forms 7 / 8 of gemm_nt_pipeline.h): FFN up-projection forward
+// C = gelu_new'(u), C2 = gelu_new(u) with u = A·B^T + bias (modeling_albert.py:225-232, activations.py:59-66), and the
+// matching backward C = (A·B^T) * aux with aux = that stash (+ column-sum partials = the FFN bias gradient). 256x256 tiles
+// (M % 256 == 0, N % 256 == 0); returns 3 for other shapes: the caller then uses forms 1 / 2 (which stash u) for BOTH.
+extern "C" int plb_launch_gemm_nt_gelud(const PlbGemmNT* p, int backward, hipStream_t stream) {
+  if (p->M % 256 || p->N % 256 || p->K % 64 || p->M <= 0 || p->N <= 0 || p->K <= 0) return 3;
+  if (!p->C || (!backward && !p->C2) || (backward && !p->aux)) return 1;
+  dim3 grid((p->M / 256) * (p->N / 256)), block(512);
+  const double mnk = (double)p->M * p->N * p->K;
+  const double bytes = 2.0 * ((double)p->M * p->K + (double)p->N * p->K) + 4.0 * p->M * p->N;
+  const int tok = plb_prof_begin(backward ? PLB_K_GEMM_NT_GELUBWD : PLB_K_GEMM_NT_GELU, stream, 2.0 * mnk, bytes);
+  if (backward) hipLaunchKernelGGL((gemm_nt_big_kernel<2, 8, false, true>), grid, block, 0, stream, *p);
+  else hipLaunchKernelGGL((gemm_nt_big_kernel<2, 7, false, true>), grid, block, 0, stream, *p);
+  plb_prof_end(tok, stream);
+  return hipGetLastError() == hipSuccess ? 0 : 2;
+}

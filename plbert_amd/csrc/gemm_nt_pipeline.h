@@ -68,7 +68,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   const int wm = uw >> 2, wn = uw & 3;
   const int nbn = p.N / TN;
   int bm, bn;
-  if constexpr (ACT >= 5) {
+  if constexpr (ACT == 5 || ACT == 6) {
     // LayerNorm forms: the nbn column tiles of a row block exchange row partials inside the launch, so they sit on
     // consecutive dispatch slots of ONE XCD (block ids b, b + 8, ...: placement is a speed / latency matter only, the
     // hand-off is agent-scope). (M / 128) % 8 == 0 is checked by the launcher.
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
             gu64_t* g = xq + (((size_t)(bm * nbn + j) * nbn + bn) * TM + tid) * 2;
             unsigned long long wa = 0, wb = 0;
             bool seen = false;
-            for (unsigned spins = 0; spins < (1u << 21); ++spins) {   // ~0.1 s: far beyond any launch
+            for (unsigned spins = 0; spins < (1u << 18); ++spins) {   // ~0.5 s of polling: far beyond any launch
               wa = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               wb = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if ((wa >> 32) == 1ull && (wb >> 32) == 1ull) { seen = true; break; }
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     }
     return;
   }
-  uint2 keep[NAH][4][NBH][2];  // ACT == 1: the packed pre-activations, for the second (gelu) image
+  uint2 keep[NAH][4][NBH][2];  // ACT == 1: the packed pre-activations, for the second (gelu) image; ACT == 7: the packed activations
   // FP8 with p.C8: the fp8 copy of the output (act 1: of gelu) that the next fp8 GEMM reads, packed 4 values per
   // register here and written through the LDS image as bytes after the bf16 outputs have left; amax of the launch
   uint32_t k8[NAH][4][NBH][2];
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
           for (int ni = 0; ni < 2; ++ni)
             rr[nh][ni] = *(const uint2*)(p.res + (size_t)m * p.ldr + ncol0 + nh * 128 + ni * 16);
       }
-      if (ACT == 2) {
+      if (ACT == 2 || ACT == 8) {
 #pragma unroll
         for (int nh = 0; nh < NBH; ++nh)
 #pragma unroll
@@ -796,12 +796,34 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
             v[2] = v[2] != 0.f ? v[2] * gelu_new_grad_f(bf_lo(ux[nh][ni].y)) : 0.f;
             v[3] = v[3] != 0.f ? v[3] * gelu_new_grad_f(bf_hi(ux[nh][ni].y)) : 0.f;
           }
+          if (ACT == 8) {  // gelu backward on a stashed DERIVATIVE (form 7 below): one multiply per value
+            v[0] = v[0] != 0.f ? v[0] * bf_lo(ux[nh][ni].x) : 0.f; v[1] = v[1] != 0.f ? v[1] * bf_hi(ux[nh][ni].x) : 0.f;
+            v[2] = v[2] != 0.f ? v[2] * bf_lo(ux[nh][ni].y) : 0.f; v[3] = v[3] != 0.f ? v[3] * bf_hi(ux[nh][ni].y) : 0.f;
+          }
+          uint2 gpk = make_uint2(0u, 0u);
+          if (ACT == 7) {
+            // gelu forward that stashes gelu_new'(u) instead of u: the sigmoid (one v_exp, one v_rcp) is shared by the
+            // activation and its derivative, so the backward epilogue multiplies by a stashed number instead of
+            // evaluating the derivative (128 evaluations per lane of a 2-waves-per-SIMD epilogue). Both are formed from
+            // the fp32 pre-activation; u itself is not kept (nothing but the derivative ever read it).
+            f32x4 gg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float x = v[r], x2 = x * x;
+              const float sg = gelu_sigmoid(x, x2);
+              gg[r] = x * sg;
+              v[r] = __builtin_fmaf(sg, x * __builtin_fmaf(x2, 0.21406444f, 1.5957691f) * (1.0f - sg), sg);
+            }
+            gpk.x = pack_bf2(gg[0], gg[1]); gpk.y = pack_bf2(gg[2], gg[3]);
+            asm volatile("" : "+v"(gpk.x), "+v"(gpk.y));  // packed NOW: carried in fp32 to the second image it spilled
+          }
           if (OUTF32) {
             if (st) *(float4*)(p.Cf + (size_t)m * p.ldcf + n0) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
             uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
             *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = o;
             if (ACT == 1) keep[mh][mi][nh][ni] = o;
+            if (ACT == 7) keep[mh][mi][nh][ni] = gpk;
             v = f32x4{bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};  // the values as stored
             if constexpr (FP8 && ACT != 1) {
               if (want8) {
@@ -824,7 +846,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
       if (r < rows_ok) *(uint4*)(cbase + (size_t)r * p.ldc + cc * 8) = v;
     }
-    if (ACT == 1) {  // gelu forward: C keeps the bf16 pre-activation u, C2 = gelu_new(u)
+    if (ACT == 1 || ACT == 7) {  // gelu forward: C keeps the bf16 pre-activation u (7: gelu_new'(u)), C2 = gelu_new(u)
       __syncthreads();
 #pragma unroll
       for (int mh = 0; mh < NAH; ++mh)
@@ -835,9 +857,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
               const uint2 o = keep[mh][mi][nh][ni];
-              uint2 g;
-              g.x = pack_bf2(gelu_new_f(bf_lo(o.x)), gelu_new_f(bf_hi(o.x)));
-              g.y = pack_bf2(gelu_new_f(bf_lo(o.y)), gelu_new_f(bf_hi(o.y)));
+              uint2 g = o;  // form 7: the activation was formed (and packed) beside its derivative
+              if (ACT == 1) {
+                g.x = pack_bf2(gelu_new_f(bf_lo(o.x)), gelu_new_f(bf_hi(o.x)));
+                g.y = pack_bf2(gelu_new_f(bf_lo(o.y)), gelu_new_f(bf_hi(o.y)));
+              }
               *(uint2*)&smem[(mh * 128 + wm * 64 + mi * 16 + frow) * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = g;
               if constexpr (FP8) {
                 if (want8) {  // the fp8 image of gelu(u) as stored in bf16: what the bf16 path's FFN2 would read

@@ -63,6 +63,9 @@ typedef struct {
 //                    colpart[2*M/128][3][N] = per (row tile, wave half) dgamma | dbeta | column sums of C
 // Returns 3 when the shape has no fused form (the caller runs the GEMM and the LayerNorm kernel separately).
 int plb_launch_gemm_nt_ln(const PlbGemmNT* p, int mode, hipStream_t stream);
+// gelu_new with the DERIVATIVE stashed: forward C = gelu_new'(A·B^T + bias), C2 = gelu_new(..); backward C = (A·B^T) * aux
+// (aux = the forward's C; colpart as in plb_launch_gemm_nt). M % 256 == 0 and N % 256 == 0, else 3.
+int plb_launch_gemm_nt_gelud(const PlbGemmNT* p, int backward, hipStream_t stream);
 // fp8 (e4m3 weights; e4m3 or e5m2 activations / gradients) form of plb_launch_gemm_nt on the pipeline kernel.
 // Returns 3 when the shape has no big-tile form (the caller then uses the bf16 GEMM).
 int plb_launch_gemm_nt_fp8(const PlbGemmNT* p, int act, int a_bf8, hipStream_t stream);

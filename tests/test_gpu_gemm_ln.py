@@ -136,3 +136,40 @@ def test_unsupported_shapes_are_refused():
     p = t.params()
     p.M = 896                                                                # not a multiple of 1024: no fused form
     assert L.plb_launch_gemm_nt_ln(C.byref(p), 5, stream()) == 3
+
+
+def test_gelu_epilogues_with_stashed_derivative():
+    """Forms 7 / 8 of the pipeline kernel (plb_launch_gemm_nt_gelud): the FFN up-projection writes gelu_new'(u) and
+    gelu_new(u) (activations.py:59-66) from the fp32 u = A·B^T + bias; the backward GEMM multiplies by the stash and
+    leaves the column-sum partials of its output (the ffn.bias gradient)."""
+    import math
+    L = _lib.lib()
+    M, N, K = 512, 768, 256
+    A, B = randbf(M, K, seed=4), randbf(N, K, scale=0.15, seed=5)
+    bias = (torch.randn(N, generator=torch.Generator().manual_seed(6)) * 0.1).to(DEV)
+    d = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    g = torch.zeros_like(d)
+    p = _lib.PlbGemmNT()
+    p.A, p.lda, p.B, p.ldb, p.M, p.N, p.K, p.Mstore = A.data_ptr(), K, B.data_ptr(), K, M, N, K, M
+    p.bias, p.C, p.ldc, p.C2, p.ldc2 = bias.data_ptr(), d.data_ptr(), N, g.data_ptr(), N
+    assert L.plb_launch_gemm_nt_gelud(C.byref(p), 0, stream()) == 0
+    torch.cuda.synchronize()
+    u = (A.float() @ B.float().T + bias).requires_grad_(True)
+    act = 0.5 * u * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (u + 0.044715 * u ** 3)))
+    act.sum().backward()
+    assert rel_l2(g.float(), act.detach()) < 4e-3
+    assert rel_l2(d.float(), u.grad) < 4e-3 and (d.float() - u.grad).abs().max() < 1e-2
+    # backward: (A2·B2^T) * stash, + column sums of what was stored
+    A2, B2 = randbf(M, K, seed=7), randbf(N, K, scale=0.15, seed=8)
+    du = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    colp = torch.zeros(2 * M // 256, N, dtype=torch.float32, device=DEV)
+    q = _lib.PlbGemmNT()
+    q.A, q.lda, q.B, q.ldb, q.M, q.N, q.K, q.Mstore = A2.data_ptr(), K, B2.data_ptr(), K, M, N, K, M
+    q.aux, q.ldaux, q.C, q.ldc, q.colpart = d.data_ptr(), N, du.data_ptr(), N, colp.data_ptr()
+    assert L.plb_launch_gemm_nt_gelud(C.byref(q), 1, stream()) == 0
+    torch.cuda.synchronize()
+    ref = (A2.float() @ B2.float().T) * d.float()
+    assert rel_l2(du.float(), ref) < 4e-3
+    assert rel_l2(colp.double().sum(0), du.double().sum(0)) < 1e-5
+    q.M = 384                                                                # not a 256-multiple: no such form
+    assert L.plb_launch_gemm_nt_gelud(C.byref(q), 1, stream()) == 3

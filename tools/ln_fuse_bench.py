@@ -65,6 +65,14 @@ def one(M, N, K):
     t_ub = timeit(unf_b)
     gb.C, gb.aux, gb.ldaux, gb.colpart = dx.data_ptr(), pre.data_ptr(), N, colp.data_ptr()
     t_fb = timeit(lambda: L.plb_launch_gemm_nt_ln(C.byref(gb), 6, s))
+    # timing experiments (wrong results): every row's pre segment from one line / no residual — what the partial-line
+    # epilogue loads cost
+    gb.ldaux = 0
+    t_fb_noaux = timeit(lambda: L.plb_launch_gemm_nt_ln(C.byref(gb), 6, s))
+    gb.ldaux = N
+    gb.res = None
+    t_fb_nores = timeit(lambda: L.plb_launch_gemm_nt_ln(C.byref(gb), 6, s))
+    print(f"    bwd fused with the pre loads served from one line {t_fb_noaux:6.1f}, without residual {t_fb_nores:6.1f} us")
     assert int(err.item()) == 0
     print(f"M {M:6d} N {N:5d} K {K:5d}: GEMM alone {t_gemm:6.1f} | fwd GEMM+LN {t_uf:6.1f} -> fused {t_ff:6.1f} us | "
           f"bwd GEMM+LN {t_ub:6.1f} -> fused {t_fb:6.1f} us", flush=True)
