@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
   int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
   if (rows_valid > 0)
-    store_transposed(o0, o1, inv, patch, p.ctx + (tok0 + q0) * p.ldctx + hd * 64, p.ldctx, rows_valid, lane);
+    store_transposed<(ATTN_OUT_NT & 1) != 0>(o0, o1, inv, patch, p.ctx + (tok0 + q0) * p.ldctx + hd * 64, p.ldctx, rows_valid, lane);
 }
 
 // ------------------------------------------------------------------------------------- backward dQ
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
   // bias-gradient partial row of this wave: [(b * QT + q tile) * 4 + wave][3H], columns hd*64.. of the Q block
   float* cp = p.colpart ? p.colpart + ((size_t)(b * QT + bx) * 4 + wave) * (3 * H) + hd * 64 : nullptr;
   if (rows_valid > 0)
-    store_transposed(dq0, dq1, p.scale, patch, p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64, p.lddqkv, rows_valid, lane, cp,
+    store_transposed<(ATTN_OUT_NT & 2) != 0>(dq0, dq1, p.scale, patch, p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64, p.lddqkv, rows_valid, lane, cp,
                      p.colpart_accumulate != 0);
   else if (cp && !p.colpart_accumulate) cp[lane] = 0.f;
 }
@@ -470,9 +470,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   if (rows_valid > 0) {
     bf16_t* out = p.dqkv + (tok0 + key0) * p.lddqkv + hd * 64;
     const bool accq = p.colpart_accumulate != 0;
-    store_transposed(dk0, dk1, p.scale, patch, out + H, p.lddqkv, rows_valid, lane, cp ? cp + H : nullptr, accq);
+    store_transposed<(ATTN_OUT_NT & 4) != 0>(dk0, dk1, p.scale, patch, out + H, p.lddqkv, rows_valid, lane, cp ? cp + H : nullptr, accq);
     __builtin_amdgcn_wave_barrier();
-    store_transposed(dv0, dv1, 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane, cp ? cp + 2 * H : nullptr, accq);
+    store_transposed<(ATTN_OUT_NT & 4) != 0>(dv0, dv1, 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane, cp ? cp + 2 * H : nullptr, accq);
   } else if (cp && !p.colpart_accumulate) {
     cp[H + lane] = 0.f;
     cp[2 * H + lane] = 0.f;

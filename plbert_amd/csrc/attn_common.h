@@ -106,6 +106,11 @@ DEVI f32x16 zero16() {
 // colsum (optional): this wave's 64 column sums of the rows it stored (the values as rounded to bf16) — lane c sums
 // column c of the patch. The engine adds these few partial rows up into the Q/K/V bias gradient instead of re-reading
 // the stacked [L*T, 3H] gradient (906 MB per step at config A).
+// NT: the rows leave with the non-temporal hint (ATTN_OUT_NT picks the kernels: 1 forward, 2 dQ, 4 dK / dV, 8 fused).
+#ifndef ATTN_OUT_NT
+#define ATTN_OUT_NT 0
+#endif
+template <bool NT = false>
 DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_t* patch, bf16_t* gout, int ldo,
                            int rows_valid, int lane, float* colsum = nullptr, bool accumulate = false) {
   constexpr int PS = 72;  // elements per patch row (144 B)
@@ -127,7 +132,11 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
   for (int i = 0; i < 4; ++i) {
     const int id = lane + 64 * i, row = id >> 3, c = id & 7;
     uint4 v = *(const uint4*)&patch[row * PS + c * 8];
-    if (row < rows_valid && (!(ATTN_DBG & 128) || v.x == 0x12345678u)) *(uint4*)(gout + (size_t)row * ldo + c * 8) = v;
+    if (row < rows_valid && (!(ATTN_DBG & 128) || v.x == 0x12345678u)) {
+      typedef unsigned int u32x4nt_ __attribute__((ext_vector_type(4)));
+      if constexpr (NT) __builtin_nontemporal_store(u32x4nt_{v.x, v.y, v.z, v.w}, (u32x4nt_*)(gout + (size_t)row * ldo + c * 8));
+      else *(uint4*)(gout + (size_t)row * ldo + c * 8) = v;
+    }
   }
   if (colsum && !(ATTN_DBG & 64)) {
     float sacc = 0.f;

@@ -8,6 +8,24 @@
 #ifndef NT_DBG
 #define NT_DBG 0
 #endif
+// bf16 output tiles leave as full lines, those of the gelu and LayerNorm forms with the non-temporal hint: 25-134 MB of
+// output per launch otherwise sweep the weights and the activation panels out of the XCD's 4 MB L2 (PMC: the 2-round gelu
+// launches fetched their weights once per round). Measured per form on one box (profiles/r03_nt_store_ab.txt): gelu forms
+// -0.15 ms/step, gelu + LayerNorm forms -0.29 ms/step; on the plain launches the hint is neutral (the QKV output is what
+// the attention kernel reads next: it lost what the GEMM won). NT_OUT_NT (bit mask, A/B builds): 1 plain launches (act 0),
+// 2 gelu forms (1, 2, 7, 8), 4 LayerNorm forms (5, 6), 8 only the pre-LayerNorm image of form 5.
+#ifndef NT_OUT_NT
+#define NT_OUT_NT 6
+#endif
+typedef unsigned int u32x4nt __attribute__((ext_vector_type(4)));
+#define OUT_STORE(ptr, v)                                                                               \
+  do {                                                                                                  \
+    if constexpr (((NT_OUT_NT & 1) && ACT == 0) || ((NT_OUT_NT & 2) && (ACT == 1 || ACT == 2 || ACT == 7 || ACT == 8)) || \
+                  ((NT_OUT_NT & 4) && (ACT == 5 || ACT == 6)))                                          \
+      __builtin_nontemporal_store(u32x4nt{(v).x, (v).y, (v).z, (v).w}, (u32x4nt*)(ptr));                \
+    else                                                                                                \
+      *(uint4*)(ptr) = (v);                                                                             \
+  } while (0)
 
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 typedef int i32x8v __attribute__((ext_vector_type(8)));
@@ -56,6 +74,10 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // assignment of k to (lane >> 4, byte) is valid as long as A and B use the same one (tools/probe_fp8.hip), so a lane
 // keeps the bf16 kernel's chunks {fq, 4 + fq} of a row: the conflict-free image needs no change. The accumulators are
 // multiplied by the two per-tensor dequantisation factors in the epilogue.
+// (A persistent form — 256 workgroups walking the tiles of a multi-round launch, stores left to drain under the next
+// tile's K loop — was built and measured in round 3: 64.9 vs 65.0 us on the 3-round QKV launch, 71.7 vs 72.8 / 76.2 vs
+// 77.1 us on the gelu forms. The hardware already turns workgroups over without waiting for their stores; what a round
+// costs beside its K loop is inside the workgroup: tools/nt_stamps.py, DESIGN.md section 6. Not kept.)
 template <int V, int ACT, bool OUTF32, bool PF, bool FP8 = false, bool ABF8 = false>
 __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   constexpr int NAH = (V == 2) ? 2 : 1;
@@ -82,6 +104,10 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   const int nk = p.K / EPK;
 #if NT_DBG & 16
   const unsigned long long dbg_c0 = __builtin_readcyclecounter(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#if NT_DBG & 32
+  unsigned long long st_[6];
+  st_[0] = __builtin_amdgcn_s_memrealtime();
 #endif
 
   // ---- staging: each wave DMAs rows [(2w+j)*8, +8) of a half-tile, j = 0,1 (1 KiB per instruction);
@@ -248,6 +274,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   }
   BARRIER();
   PRO = false;
+#if NT_DBG & 32
+  st_[1] = __builtin_amdgcn_s_memrealtime();
+#endif
   if constexpr (PF) {
     // ---- interleaved loop (default). Measured on the staggered loop (tools/build_dbg.sh): MFMA, fragment
     // reads and DMA cost 0.64 + 0.41 + 0.29 us per K-tile and the K-tile takes their SUM — a wave issues in
@@ -441,6 +470,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   // of a 28 us 16384x768x768 launch, 19 of 79 us at N = 2304). The tile is packed into a padded LDS
   // image (the ring is free now) and written out as full 128-B lines, 16 B per lane.
   // Big-tile shapes have N % TN == 0; rows >= Mstore are computed but not stored.
+#if NT_DBG & 32
+  st_[2] = __builtin_amdgcn_s_memrealtime();
+#endif
   constexpr int OROW = TN + 16;  // image row stride (elements): +32 B rotates the rows over the banks
   static_assert(TM * OROW <= RING * HT, "output image must fit the ring");
   f32x4 csum[NBH][2];  // column sums of this wave's rows (only when p.colpart is set)
@@ -620,7 +652,10 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       for (int c = tid; c < TM * CPR; c += 512) {
         const int r = c / CPR, cc = c - r * CPR;
         const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
-        if (r < rows_ok) *(uint4*)(cbase + (size_t)r * p.ldc + cc * 8) = v;
+        if (r < rows_ok) {
+          if constexpr (NT_OUT_NT & 8) __builtin_nontemporal_store(u32x4nt{v.x, v.y, v.z, v.w}, (u32x4nt*)(cbase + (size_t)r * p.ldc + cc * 8));
+          else OUT_STORE((cbase + (size_t)r * p.ldc + cc * 8), v);
+        }
       }
     }
     if (tid < TM) {   // collect and merge the nbn partials of row tid in tile order (the same arithmetic on every tile)
@@ -729,7 +764,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       for (int c = tid; c < TM * CPR; c += 512) {
         const int r = c / CPR, cc = c - r * CPR;
         const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
-        if (r < rows_ok) *(uint4*)(obase + (size_t)r * ldo + cc * 8) = v;
+        if (r < rows_ok) OUT_STORE((obase + (size_t)r * ldo + cc * 8), v);
       }
     }
     return;
@@ -840,11 +875,14 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     bf16_t* const cbase = p.C + (size_t)(bm * TM) * p.ldc + bn * TN;
     const int rows_ok = p.Mstore - bm * TM;  // rows of this tile that are stored
     __syncthreads();
+#if NT_DBG & 32
+    st_[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll 4
     for (int c = tid; c < TM * CPR; c += 512) {
       const int r = c / CPR, cc = c - r * CPR;
       const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
-      if (r < rows_ok) *(uint4*)(cbase + (size_t)r * p.ldc + cc * 8) = v;
+      if (r < rows_ok) OUT_STORE((cbase + (size_t)r * p.ldc + cc * 8), v);
     }
     if (ACT == 1 || ACT == 7) {  // gelu forward: C keeps the bf16 pre-activation u (7: gelu_new'(u)), C2 = gelu_new(u)
       __syncthreads();
@@ -878,7 +916,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       for (int c = tid; c < TM * CPR; c += 512) {
         const int r = c / CPR, cc = c - r * CPR;
         const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
-        if (r < rows_ok) *(uint4*)(gbase + (size_t)r * p.ldc2 + cc * 8) = v;
+        if (r < rows_ok) OUT_STORE((gbase + (size_t)r * p.ldc2 + cc * 8), v);
       }
     }
     if constexpr (FP8) {
@@ -930,6 +968,14 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
               make_float4(v[0], v[1], v[2], v[3]);
       }
   }
+#if NT_DBG & 32
+  st_[4] = __builtin_amdgcn_s_memrealtime();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  st_[5] = __builtin_amdgcn_s_memrealtime();
+  if ((blockIdx.x % 256) == 17 && tid == 0)
+    printf("blk %d: start %llu | fill %llu | kloop %llu | image %llu | stores issued %llu | drained %llu (x10 ns)\n", (int)blockIdx.x,
+           st_[0] % 1000000ull, st_[1] - st_[0], st_[2] - st_[1], st_[3] - st_[2], st_[4] - st_[3], st_[5] - st_[4]);
+#endif
 }
 
 }  // namespace
