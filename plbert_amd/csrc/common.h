@@ -27,6 +27,20 @@ DEVI uint32_t pack_bf2(float lo, float hi) {
 DEVI float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
 DEVI float bf_hi(uint32_t u) { return __uint_as_float(u & 0xFFFF0000u); }
 
+// Sum over the 16 lanes of a DPP row (lanes 16 r .. 16 r + 15), the total in every lane: two quad permutes and two row
+// rotations, folded into the adds as v_add_f32_dpp — no LDS traffic. (__shfl_xor compiles to ds_bpermute_b32: an LDS
+// round trip and an lgkmcnt wait per step.) Fixed order: bitwise reproducible.
+template <int CTRL>
+DEVI float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+DEVI float row16_sum(float v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x128>(v);  // row_ror:8
+  return v;
+}
 DEVI float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -564,6 +564,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     typedef __attribute__((address_space(1))) unsigned long long gu64_t;
     gu64_t* const xq = (gu64_t*)(p.ln_xchg);
     const float invN = 1.0f / (float)p.N;
+    // (Round 3, measured and dropped: the forward form has ~60 registers to spare, so its 24 residual loads were requested
+    // from inside the last K-tile. As one burst behind the last counted wait: first pass 7.8 -> 3.9 us, K loop + 4.8 us
+    // — in MFMA layout a load instruction is 16 partial lines and the burst held the waves at the next barrier. One
+    // load per MFMA shadow behind per-slot branches: + 0.3 us on EVERY K-tile. A second copy of the K-tile body for the
+    // last K-tile (one branch per K-tile): hipcc spilled 413 registers. tools/nt_stamps.py prints these phases.)
     // per-tile row partials (a, b): forward a = sum x, b = sum x^2 ; backward a = sum dy*gamma, b = sum dy*gamma*xhat
     // every residual / pre segment of the tile is requested up front: in MFMA layout a load instruction touches 16 rows x
     // 32 B, and one dependent round trip per 16-row slab (the plain epilogue's form) cost this epilogue ~10 us per launch
@@ -625,6 +630,10 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       if (fq == 0) { tab[(lrow * 4 + wn) * 2] = a1; tab[(lrow * 4 + wn) * 2 + 1] = a2; }
     }
     __syncthreads();
+#if NT_DBG & 32
+    unsigned long long ls_[6];
+    ls_[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     float pa = 0.f, pb = 0.f;   // this tile's partial of row tid (threads 0..127)
     if (tid < TM) {
       pa = (tab[(tid * 4 + 0) * 2] + tab[(tid * 4 + 1) * 2]) + (tab[(tid * 4 + 2) * 2] + tab[(tid * 4 + 3) * 2]);
@@ -658,6 +667,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
         }
       }
     }
+#if NT_DBG & 32
+    ls_[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (tid < TM) {   // collect and merge the nbn partials of row tid in tile order (the same arithmetic on every tile)
       float qa[4], qb[4];
 #pragma unroll
@@ -702,6 +714,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       }
     }
     __syncthreads();   // also: every thread's reads of image 1 have retired (its stores consumed them)
+#if NT_DBG & 32
+    ls_[2] = __builtin_amdgcn_s_memrealtime();
+#endif
     // second pass, one 4-column group of the lane at a time (its 4 rows innermost): the three column sums of the backward
     // then need 12 registers instead of 72, which is what lets the pre segments of the first pass stay in registers
     float t0[4], t1[4];
@@ -743,11 +758,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #pragma unroll
           for (int q3 = 0; q3 < 3; ++q3) {
             f32x4 v = q3 == 0 ? dg : q3 == 1 ? db : cs;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-              v[0] += __shfl_xor(v[0], o, 64); v[1] += __shfl_xor(v[1], o, 64);
-              v[2] += __shfl_xor(v[2], o, 64); v[3] += __shfl_xor(v[3], o, 64);
-            }
+            v = f32x4{row16_sum(v[0]), row16_sum(v[1]), row16_sum(v[2]), row16_sum(v[3])};
             if (frow == 0)
               *(float4*)(p.colpart + ((size_t)(bm * 2 + wm) * 3 + q3) * p.N + bn * TN + nh * 128 + wn * 32 + ni * 16 + fq * 4) =
                   make_float4(v[0], v[1], v[2], v[3]);
@@ -755,6 +766,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
         }
       }
     __syncthreads();
+#if NT_DBG & 32
+    ls_[3] = __builtin_amdgcn_s_memrealtime();
+#endif
     {
       constexpr int CPR = TN / 8;
       bf16_t* const obase = (ACT == 5 ? p.C2 + (size_t)(bm * TM) * p.ldc2 : p.C + (size_t)(bm * TM) * p.ldc) + bn * TN;
@@ -767,6 +781,15 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
         if (r < rows_ok) OUT_STORE((obase + (size_t)r * ldo + cc * 8), v);
       }
     }
+#if NT_DBG & 32
+    ls_[4] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ls_[5] = __builtin_amdgcn_s_memrealtime();
+    if ((blockIdx.x % 256) == 17 && tid == 0)
+      printf("blk %d LN form %d: fill %llu | kloop %llu | pass 1 %llu | publish + image 1 out %llu | partners' partials %llu | pass 2 %llu | "
+             "stores issued %llu | drained %llu (x10 ns)\n", (int)blockIdx.x, ACT, st_[1] - st_[0], st_[2] - st_[1], ls_[0] - st_[2],
+             ls_[1] - ls_[0], ls_[2] - ls_[1], ls_[3] - ls_[2], ls_[4] - ls_[3], ls_[5] - ls_[4]);
+#endif
     return;
   }
   uint2 keep[NAH][4][NBH][2];  // ACT == 1: the packed pre-activations, for the second (gelu) image; ACT == 7: the packed activations
@@ -958,11 +981,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         f32x4 v = csum[nh][ni];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          v[0] += __shfl_xor(v[0], o, 64); v[1] += __shfl_xor(v[1], o, 64);
-          v[2] += __shfl_xor(v[2], o, 64); v[3] += __shfl_xor(v[3], o, 64);
-        }
+        v = f32x4{row16_sum(v[0]), row16_sum(v[1]), row16_sum(v[2]), row16_sum(v[3])};
         if (frow == 0)
           *(float4*)(p.colpart + (size_t)(bm * 2 + wm) * p.N + bn * TN + nh * 128 + wn * 32 + ni * 16 + fq * 4) =
               make_float4(v[0], v[1], v[2], v[3]);

@@ -64,7 +64,8 @@ def _fwd(t, reps=1):
     return outs
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (2048, 768, 2048), (1024, 1024, 1024), (16384, 768, 768)])
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (2048, 768, 2048), (1024, 1024, 1024), (16384, 768, 768),
+                                   (1024, 768, 64), (1024, 768, 128), (1024, 768, 192), (1024, 1024, 64), (1024, 1024, 128)])
 def test_gemm_layernorm_forward(M, N, K):
     t = Ln(M, N, K, seed=M + N)
     pre, y, mean, rstd = _fwd(t)[0]

@@ -8,7 +8,8 @@ P=plbert_amd
 mkdir -p $P/build/dbg
 for n in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DNT_DBG=$n -x hip -c $P/csrc/gemm_big.hip -o $P/build/dbg/gemm_big_$n.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DNT_DBG=$n -x hip -c $P/csrc/gemm_ln.hip -o $P/build/dbg/gemm_ln_$n.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,-Bsymbolic -o $P/build/dbg/libplbert_dbg$n.so \
-    $(ls $P/build/*.o | grep -v /gemm_big.o) $P/build/dbg/gemm_big_$n.o
+    $(ls $P/build/*.o | grep -v "/gemm_big.o\|/gemm_ln.o") $P/build/dbg/gemm_big_$n.o $P/build/dbg/gemm_ln_$n.o
   echo built $P/build/dbg/libplbert_dbg$n.so
 done
