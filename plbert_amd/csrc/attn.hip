@@ -467,15 +467,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
   int rows_valid = S - key0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
   float* cp = p.colpart ? p.colpart + ((size_t)(b * QT + bx) * 4 + wave) * (3 * H) + hd * 64 : nullptr;
+  // the lane id is re-derived here (mbcnt, behind an opaque copy): carried across the loop for these few lines it — and
+  // the thread id it comes from — were the kernel's two spilled registers (256 VGPRs in the loop)
+  int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(lane_e));
   if (rows_valid > 0) {
     bf16_t* out = p.dqkv + (tok0 + key0) * p.lddqkv + hd * 64;
     const bool accq = p.colpart_accumulate != 0;
-    store_transposed<(ATTN_OUT_NT & 4) != 0>(dk0, dk1, p.scale, patch, out + H, p.lddqkv, rows_valid, lane, cp ? cp + H : nullptr, accq);
+    store_transposed<(ATTN_OUT_NT & 4) != 0>(dk0, dk1, p.scale, patch, out + H, p.lddqkv, rows_valid, lane_e, cp ? cp + H : nullptr, accq);
     __builtin_amdgcn_wave_barrier();
-    store_transposed<(ATTN_OUT_NT & 4) != 0>(dv0, dv1, 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane, cp ? cp + 2 * H : nullptr, accq);
+    store_transposed<(ATTN_OUT_NT & 4) != 0>(dv0, dv1, 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane_e, cp ? cp + 2 * H : nullptr, accq);
   } else if (cp && !p.colpart_accumulate) {
-    cp[H + lane] = 0.f;
-    cp[2 * H + lane] = 0.f;
+    cp[H + lane_e] = 0.f;
+    cp[2 * H + lane_e] = 0.f;
   }
 }
 

@@ -36,7 +36,8 @@ int launch_big(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream) {
     if (act != 0) return 1;
     hipLaunchKernelGGL((gemm_nt_big_kernel<V, 0, true, PF>), grid, block, 0, stream, *p);
   } else if (act == 0) {
-    hipLaunchKernelGGL((gemm_nt_big_kernel<V, 0, false, PF>), grid, block, 0, stream, *p);
+    if (p->colpart) hipLaunchKernelGGL((gemm_nt_big_kernel<V, 0, false, PF>), grid, block, 0, stream, *p);
+    else hipLaunchKernelGGL((gemm_nt_big_kernel<V, 0, false, PF, false, false, true>), grid, block, 0, stream, *p);
   } else if (act == 1) {
     hipLaunchKernelGGL((gemm_nt_big_kernel<V, 1, false, PF>), grid, block, 0, stream, *p);
   } else if (act == 2) {

@@ -40,7 +40,8 @@ extern "C" int plb_launch_gemm_nt_gelud(const PlbGemmNT* p, int backward, hipStr
   const double bytes = 2.0 * ((double)p->M * p->K + (double)p->N * p->K) + 4.0 * p->M * p->N;
   const int tok = plb_prof_begin(backward ? PLB_K_GEMM_NT_GELUBWD : PLB_K_GEMM_NT_GELU, stream, 2.0 * mnk, bytes);
   if (backward) hipLaunchKernelGGL((gemm_nt_big_kernel<2, 8, false, true>), grid, block, 0, stream, *p);
-  else hipLaunchKernelGGL((gemm_nt_big_kernel<2, 7, false, true>), grid, block, 0, stream, *p);
+  else if (p->colpart) hipLaunchKernelGGL((gemm_nt_big_kernel<2, 7, false, true>), grid, block, 0, stream, *p);
+  else hipLaunchKernelGGL((gemm_nt_big_kernel<2, 7, false, true, false, false, true>), grid, block, 0, stream, *p);
   plb_prof_end(tok, stream);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }

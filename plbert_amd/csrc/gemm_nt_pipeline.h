@@ -78,7 +78,9 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // tile's K loop — was built and measured in round 3: 64.9 vs 65.0 us on the 3-round QKV launch, 71.7 vs 72.8 / 76.2 vs
 // 77.1 us on the gelu forms. The hardware already turns workgroups over without waiting for their stores; what a round
 // costs beside its K loop is inside the workgroup: tools/nt_stamps.py, DESIGN.md section 6. Not kept.)
-template <int V, int ACT, bool OUTF32, bool PF, bool FP8 = false, bool ABF8 = false>
+// NOCS: the launch has no column-sum output (p.colpart == nullptr, checked by the launcher): the epilogue's per-value
+// re-expansion of the stored bf16 and its running column sums (a third of the plain epilogue's arithmetic) are compiled out.
+template <int V, int ACT, bool OUTF32, bool PF, bool FP8 = false, bool ABF8 = false, bool NOCS = false>
 __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   constexpr int NAH = (V == 2) ? 2 : 1;
   constexpr int NBH = (V == 3) ? 3 : 2;
@@ -890,7 +892,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
               }
             }
           }
-          if (st) csum[nh][ni] += v;
+          if (!NOCS && st) csum[nh][ni] += v;
         }
     }
   if (!OUTF32) {
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       }
     }
   }
-  if (p.colpart) {
+  if (!NOCS && p.colpart) {
     // Bias gradient of the producing Linear for free: sum the stored values over this wave's 64*NAH rows
     // (16 lanes hold 16 different rows of the same 4 columns) and write ONE partial row per (row tile, wm):
     // colpart[(bm*2 + wm)][n]; a fixed-order column sum over these few rows finishes it (deterministic).
