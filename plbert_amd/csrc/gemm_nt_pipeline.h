@@ -794,7 +794,13 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #endif
     return;
   }
-  uint2 keep[NAH][4][NBH][2];  // ACT == 1: the packed pre-activations, for the second (gelu) image; ACT == 7: the packed activations
+  // Forms 7 / 8: the gelu'(u) stash is private to this pair of launches (same tiles, same lane roles), so it lives in
+  // LANE layout — tile t, slab (mh, mi), column half nh: 512 consecutive 16-byte items, one per thread = {ni 0, ni 1} of
+  // the lane's 4-column groups. Form 7 stores it straight from the registers (no LDS image, no second store pass),
+  // form 8 reads it back as full 1-KiB wave accesses. Row-major, a lane's 8-byte segments were 16 partial lines per load
+  // instruction: 8.0 us of form 8's epilogue against 2.7 us of arithmetic (tools/nt_stamps.py).
+  uint4* const lane_stash = reinterpret_cast<uint4*>(ACT == 7 ? p.C : const_cast<bf16_t*>(p.aux));
+  uint2 keep[NAH][4][NBH][2];  // ACT == 1: the packed pre-activations, for the second (gelu) image
   // FP8 with p.C8: the fp8 copy of the output (act 1: of gelu) that the next fp8 GEMM reads, packed 4 values per
   // register here and written through the LDS image as bytes after the bf16 outputs have left; amax of the launch
   uint32_t k8[NAH][4][NBH][2];
@@ -815,12 +821,20 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
           for (int ni = 0; ni < 2; ++ni)
             rr[nh][ni] = *(const uint2*)(p.res + (size_t)m * p.ldr + ncol0 + nh * 128 + ni * 16);
       }
-      if (ACT == 2 || ACT == 8) {
+      if (ACT == 2) {
 #pragma unroll
         for (int nh = 0; nh < NBH; ++nh)
 #pragma unroll
           for (int ni = 0; ni < 2; ++ni)
             ux[nh][ni] = *(const uint2*)(p.aux + (size_t)m * p.ldaux + ncol0 + nh * 128 + ni * 16);
+      }
+      if (ACT == 8) {
+        // the stash of form 7 in LANE layout (see there): this lane's 16 bytes of slab (mh, mi), column half nh
+#pragma unroll
+        for (int nh = 0; nh < NBH; ++nh) {
+          const uint4 q = lane_stash[((size_t)(bm * nbn + bn) * (NAH * 4 * NBH) + (mh * 4 + mi) * NBH + nh) * 512 + tid];
+          ux[nh][0] = make_uint2(q.x, q.y); ux[nh][1] = make_uint2(q.z, q.w);
+        }
       }
       const bool st = m < p.Mstore;
       // ACT == 4, fused GEMM + cross-entropy pass 2: the logits are recomputed and leave as the gradient
@@ -828,6 +842,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       float ce_l = 0.f, ce_wt = 0.f;
       int ce_t = -1;
       if (ACT == 4) { ce_l = p.ce_lse[m]; ce_wt = p.ce_w[m]; ce_t = (int)p.ce_tgt[m]; }
+      uint2 dpair = make_uint2(0u, 0u);
 #pragma unroll
       for (int nh = 0; nh < NBH; ++nh)
 #pragma unroll
@@ -881,9 +896,16 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
             if (st) *(float4*)(p.Cf + (size_t)m * p.ldcf + n0) = make_float4(v[0], v[1], v[2], v[3]);
           } else {
             uint2 o; o.x = pack_bf2(v[0], v[1]); o.y = pack_bf2(v[2], v[3]);
-            *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = o;
+            if (ACT == 7) {   // derivative -> lane-layout stash (both ni of a column half make one 16-byte item); image <- activation
+              if (ni == 0) dpair = o;
+              else   // read once, a backward pass later: non-temporal like the other outputs of the gelu forms
+                __builtin_nontemporal_store(u32x4nt{dpair.x, dpair.y, o.x, o.y},
+                    (u32x4nt*)(lane_stash + ((size_t)(bm * nbn + bn) * (NAH * 4 * NBH) + (mh * 4 + mi) * NBH + nh) * 512 + tid));
+              *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = gpk;
+            } else {
+              *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = o;
+            }
             if (ACT == 1) keep[mh][mi][nh][ni] = o;
-            if (ACT == 7) keep[mh][mi][nh][ni] = gpk;
             v = f32x4{bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};  // the values as stored
             if constexpr (FP8 && ACT != 1) {
               if (want8) {
@@ -897,7 +919,8 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     }
   if (!OUTF32) {
     constexpr int CPR = TN / 8;  // 16-B chunks per tile row
-    bf16_t* const cbase = p.C + (size_t)(bm * TM) * p.ldc + bn * TN;
+    const int ldimg = ACT == 7 ? p.ldc2 : p.ldc;   // form 7: the image is gelu(u) -> C2 (C is the lane-layout stash)
+    bf16_t* const cbase = (ACT == 7 ? p.C2 : p.C) + (size_t)(bm * TM) * ldimg + bn * TN;
     const int rows_ok = p.Mstore - bm * TM;  // rows of this tile that are stored
     __syncthreads();
 #if NT_DBG & 32
@@ -907,9 +930,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     for (int c = tid; c < TM * CPR; c += 512) {
       const int r = c / CPR, cc = c - r * CPR;
       const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
-      if (r < rows_ok) OUT_STORE((cbase + (size_t)r * p.ldc + cc * 8), v);
+      if (r < rows_ok) OUT_STORE((cbase + (size_t)r * ldimg + cc * 8), v);
     }
-    if (ACT == 1 || ACT == 7) {  // gelu forward: C keeps the bf16 pre-activation u (7: gelu_new'(u)), C2 = gelu_new(u)
+    if (ACT == 1) {  // gelu forward: C keeps the bf16 pre-activation u, C2 = gelu_new(u)
       __syncthreads();
 #pragma unroll
       for (int mh = 0; mh < NAH; ++mh)
@@ -920,11 +943,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
               const uint2 o = keep[mh][mi][nh][ni];
-              uint2 g = o;  // form 7: the activation was formed (and packed) beside its derivative
-              if (ACT == 1) {
-                g.x = pack_bf2(gelu_new_f(bf_lo(o.x)), gelu_new_f(bf_hi(o.x)));
-                g.y = pack_bf2(gelu_new_f(bf_lo(o.y)), gelu_new_f(bf_hi(o.y)));
-              }
+              uint2 g;
+              g.x = pack_bf2(gelu_new_f(bf_lo(o.x)), gelu_new_f(bf_hi(o.x)));
+              g.y = pack_bf2(gelu_new_f(bf_lo(o.y)), gelu_new_f(bf_hi(o.y)));
               *(uint2*)&smem[(mh * 128 + wm * 64 + mi * 16 + frow) * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = g;
               if constexpr (FP8) {
                 if (want8) {  // the fp8 image of gelu(u) as stored in bf16: what the bf16 path's FFN2 would read

@@ -139,13 +139,34 @@ def test_unsupported_shapes_are_refused():
     assert L.plb_launch_gemm_nt_ln(C.byref(p), 5, stream()) == 3
 
 
+def lane_stash_to_rows(blob, M, N):
+    """The gelu'(u) stash of forms 7 / 8 is in LANE layout (csrc/gemm_nt_pipeline.h): per 256x256 tile t (row-major tile
+    order), slab (mh, mi) and column half nh, 512 consecutive 16-byte items, one per thread = {ni 0, ni 1} x 4 columns."""
+    nbn = N // 256
+    t = torch.arange((M // 256) * nbn, device=blob.device).view(-1, 1, 1, 1, 1, 1, 1)
+    mh = torch.arange(2, device=blob.device).view(1, -1, 1, 1, 1, 1, 1)
+    mi = torch.arange(4, device=blob.device).view(1, 1, -1, 1, 1, 1, 1)
+    nh = torch.arange(2, device=blob.device).view(1, 1, 1, -1, 1, 1, 1)
+    tid = torch.arange(512, device=blob.device).view(1, 1, 1, 1, -1, 1, 1)
+    ni = torch.arange(2, device=blob.device).view(1, 1, 1, 1, 1, -1, 1)
+    r = torch.arange(4, device=blob.device).view(1, 1, 1, 1, 1, 1, -1)
+    uw, lane = tid >> 6, tid & 63
+    wm, wn, frow, fq = uw >> 2, uw & 3, lane & 15, lane >> 4
+    row = (t // nbn) * 256 + mh * 128 + wm * 64 + mi * 16 + frow
+    col = (t % nbn) * 256 + nh * 128 + wn * 32 + ni * 16 + fq * 4 + r
+    out = torch.empty(M, N, dtype=blob.dtype, device=blob.device)
+    row, col = torch.broadcast_tensors(row, col)
+    out[row.reshape(-1), col.reshape(-1)] = blob.reshape(-1)   # the blob's element order IS (t, mh, mi, nh, tid, ni, r)
+    return out
+
+
 def test_gelu_epilogues_with_stashed_derivative():
     """Forms 7 / 8 of the pipeline kernel (plb_launch_gemm_nt_gelud): the FFN up-projection writes gelu_new'(u) and
     gelu_new(u) (activations.py:59-66) from the fp32 u = A·B^T + bias; the backward GEMM multiplies by the stash and
     leaves the column-sum partials of its output (the ffn.bias gradient)."""
     import math
     L = _lib.lib()
-    M, N, K = 512, 768, 256
+    M, N, K = 768, 768, 256
     A, B = randbf(M, K, seed=4), randbf(N, K, scale=0.15, seed=5)
     bias = (torch.randn(N, generator=torch.Generator().manual_seed(6)) * 0.1).to(DEV)
     d = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
@@ -159,7 +180,8 @@ def test_gelu_epilogues_with_stashed_derivative():
     act = 0.5 * u * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (u + 0.044715 * u ** 3)))
     act.sum().backward()
     assert rel_l2(g.float(), act.detach()) < 4e-3
-    assert rel_l2(d.float(), u.grad) < 4e-3 and (d.float() - u.grad).abs().max() < 1e-2
+    drows = lane_stash_to_rows(d, M, N)
+    assert rel_l2(drows.float(), u.grad) < 4e-3 and (drows.float() - u.grad).abs().max() < 1e-2
     # backward: (A2·B2^T) * stash, + column sums of what was stored
     A2, B2 = randbf(M, K, seed=7), randbf(N, K, scale=0.15, seed=8)
     du = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
@@ -169,7 +191,7 @@ def test_gelu_epilogues_with_stashed_derivative():
     q.aux, q.ldaux, q.C, q.ldc, q.colpart = d.data_ptr(), N, du.data_ptr(), N, colp.data_ptr()
     assert L.plb_launch_gemm_nt_gelud(C.byref(q), 1, stream()) == 0
     torch.cuda.synchronize()
-    ref = (A2.float() @ B2.float().T) * d.float()
+    ref = (A2.float() @ B2.float().T) * drows.float()
     assert rel_l2(du.float(), ref) < 4e-3
     assert rel_l2(colp.double().sum(0), du.double().sum(0)) < 1e-5
     q.M = 384                                                                # not a 256-multiple: no such form
