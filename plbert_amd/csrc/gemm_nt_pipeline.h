@@ -17,6 +17,12 @@
 #ifndef NT_OUT_NT
 #define NT_OUT_NT 6
 #endif
+// NT_LN_STAGE (A/B builds; default on): the LayerNorm forms bring their epilogue operand tiles (residual; form 6 also the
+// pre-LayerNorm sums) into LDS by LDS-DMA as FULL lines, in the output image's layout, instead of loading them in MFMA
+// layout (where one load instruction is 16 partial lines: 48 such loads cost the texture addresser ~6 us per operand).
+#ifndef NT_LN_STAGE
+#define NT_LN_STAGE 1
+#endif
 typedef unsigned int u32x4nt __attribute__((ext_vector_type(4)));
 #define OUT_STORE(ptr, v)                                                                               \
   do {                                                                                                  \
@@ -198,7 +204,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       for (int c = 0; c < NBH; ++c)
 #pragma unroll
         for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (ACT == 6) {
+  if constexpr (ACT == 6 && !NT_LN_STAGE) {
     // LayerNorm-backward form: the residual is the accumulators' START value (its segments arrive under the prologue's
     // DMA), not an epilogue operand — beside the kept pre segments it would not fit the epilogue's registers
     if (p.res) {
@@ -576,27 +582,84 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     // 32 B, and one dependent round trip per 16-row slab (the plain epilogue's form) cost this epilogue ~10 us per launch
     float rmean[4], rrstd[4];
     uint2 rr[4][NBH][2], ux[4][NBH][2];
+    // ---- staged operands (NT_LN_STAGE): one DMA instruction per tile row (TN / 8 active lanes x 16 B = the row's TN
+    // bf16), wave w taking rows w, w + 8, ...; destination = the row's place in the output image (row stride OROW), so
+    // every lane later finds its 8-byte segments where it will write its results: both passes work IN PLACE.
+    // R2 (behind the tables): 64 rows, for the residual of form 6 in two halves — rows of mi 0,1 then rows of mi 2,3 —
+    // the second half travelling under the first half's arithmetic.
+    constexpr int R2OFF = IMG + 128 * 4 * 2 * 4 + 128 * 2 * 4;   // bytes
+    static_assert(R2OFF + 64 * OROW * 2 <= RING * HT * 2, "staging regions must fit the LDS");
+    bf16_t* const r2 = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(smem) + R2OFF);
+    const uint32_t stg_voff = (uint32_t)lane * 16u;
+    auto stage_rows = [&](const bf16_t* src, int ld, int nrows, uint32_t lds_base, int half) {
+      // half < 0: tile rows 0 .. nrows-1 in order; half 0 / 1: the 64 rows {wm' * 64 + half * 32 + q}, stored as row wm' * 32 + q
+      for (int i = 0; i < nrows / 8; ++i) {
+        const int q = i * 8 + uw;
+        const int trow = half < 0 ? q : (q >> 5) * 64 + half * 32 + (q & 31);
+        const char* b = reinterpret_cast<const char*>(src + (size_t)(bm * TM + trow) * ld + bn * TN);
+        if (lane < TN / 8) DMA16(b, stg_voff, lds_base + (uint32_t)q * (OROW * 2));
+      }
+    };
+    const uint32_t img_lds = LDS_ADDR(&smem[0]), r2_lds = img_lds + R2OFF;
+    if constexpr (NT_LN_STAGE) {
+      if constexpr (ACT == 5) {
+        if (p.res) { stage_rows(p.res, p.ldr, TM, img_lds, -1); DMA_WAIT(); }
+        __syncthreads();
+      } else {
+        stage_rows(p.aux, p.ldaux, TM, img_lds, -1);
+        if (p.res) stage_rows(p.res, p.ldr, 64, r2_lds, 0);
+        DMA_WAIT();
+        __syncthreads();
+      }
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const int m = bm * TM + wm * 64 + mi * 16 + frow;
+      if constexpr (!NT_LN_STAGE) {
 #pragma unroll
-      for (int nh = 0; nh < NBH; ++nh)
+        for (int nh = 0; nh < NBH; ++nh)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          if constexpr (ACT == 5) { if (p.res) rr[mi][nh][ni] = *(const uint2*)(p.res + (size_t)m * p.ldr + ncol0 + nh * 128 + ni * 16); }
-          if constexpr (ACT == 6) ux[mi][nh][ni] = *(const uint2*)(p.aux + (size_t)m * p.ldaux + ncol0 + nh * 128 + ni * 16);
-        }
+          for (int ni = 0; ni < 2; ++ni) {
+            if constexpr (ACT == 5) { if (p.res) rr[mi][nh][ni] = *(const uint2*)(p.res + (size_t)m * p.ldr + ncol0 + nh * 128 + ni * 16); }
+            if constexpr (ACT == 6) ux[mi][nh][ni] = *(const uint2*)(p.aux + (size_t)m * p.ldaux + ncol0 + nh * 128 + ni * 16);
+          }
+      }
       if constexpr (ACT == 6) { rmean[mi] = p.ln_mean[m]; rrstd[mi] = p.ln_rstd[m]; }
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    // form 6, staged: the first pass runs per half of the rows (mi 0,1 | mi 2,3) around the residual's two halves
+#pragma unroll
+    for (int hf = 0; hf < ((ACT == 6 && NT_LN_STAGE) ? 2 : 1); ++hf) {
+    if constexpr (ACT == 6 && NT_LN_STAGE) {
+      if (p.res) {
+        if (hf == 1) { DMA_WAIT(); __syncthreads(); }   // second half has landed (issued below, under the first half's sums)
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq)
+#pragma unroll
+          for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+              const uint2 r = *(const uint2*)&r2[(wm * 32 + mq * 16 + frow) * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4];
+              f32x4& a = acc[0][hf * 2 + mq][nh][ni];
+              a[0] += bf_lo(r.x); a[1] += bf_hi(r.x); a[2] += bf_lo(r.y); a[3] += bf_hi(r.y);
+            }
+        if (hf == 0) { __syncthreads(); stage_rows(p.res, p.ldr, 64, r2_lds, 1); }   // R2 is free: fetch the other half
+      }
+    }
 #pragma unroll
     for (int nh = 0; nh < NBH; ++nh)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
+        if constexpr (ACT == 6 && NT_LN_STAGE) PIN();   // one column group at a time: hoisting every group's LDS reads to the top spilled
         const float4 gz = *(const float4*)(p.ln_gamma + ncol0 + nh * 128 + ni * 16);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
+        for (int mi = ((ACT == 6 && NT_LN_STAGE) ? hf * 2 : 0); mi < ((ACT == 6 && NT_LN_STAGE) ? hf * 2 + 2 : 4); ++mi) {
           const int lrow = wm * 64 + mi * 16 + frow;
+          if constexpr (NT_LN_STAGE) {
+            if constexpr (ACT == 6) PIN();
+            const uint2 t = *(const uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4];
+            if constexpr (ACT == 5) rr[mi][nh][ni] = t; else ux[mi][nh][ni] = t;
+          }
           f32x4 v = acc[0][mi][nh][ni];
           if constexpr (ACT == 5) { v[0] += bz[nh][ni].x; v[1] += bz[nh][ni].y; v[2] += bz[nh][ni].z; v[3] += bz[nh][ni].w; }
           if constexpr (ACT == 5) {
@@ -623,6 +686,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
           acc[0][mi][nh][ni] = v;   // forward: x; backward: dy (the second pass forms dy*gamma again)
         }
       }
+    }  // hf
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
       const int lrow = wm * 64 + mi * 16 + frow;
@@ -724,13 +788,18 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     float t0[4], t1[4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) { t0[mi] = tab2[(wm * 64 + mi * 16 + frow) * 2]; t1[mi] = tab2[(wm * 64 + mi * 16 + frow) * 2 + 1]; }
+    // the lane's column offset behind an opaque copy: the second pass forms its addresses afresh from this ONE register
+    // instead of carrying the first pass's 64-bit pointers across the hand-off
+    int ncol2 = ncol0;
+    asm volatile("" : "+v"(ncol2));
 #pragma unroll
     for (int nh = 0; nh < NBH; ++nh)
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
+        if constexpr (ACT == 6 && NT_LN_STAGE) PIN();
         float4 bt = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 gz = *(const float4*)(p.ln_gamma + ncol0 + nh * 128 + ni * 16);
-        if constexpr (ACT == 5) bt = *(const float4*)(p.ln_beta + ncol0 + nh * 128 + ni * 16);
+        const float4 gz = *(const float4*)(p.ln_gamma + ncol2 + nh * 128 + ni * 16);
+        if constexpr (ACT == 5) bt = *(const float4*)(p.ln_beta + ncol2 + nh * 128 + ni * 16);
         f32x4 cs = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
@@ -742,7 +811,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
                       (x[2] - t0[mi]) * t1[mi] * gz.z + bt.z, (x[3] - t0[mi]) * t1[mi] * gz.w + bt.w};
           } else {
             const float mu = rmean[mi], rs = rrstd[mi];
-            uint2 u = ux[mi][nh][ni];
+            uint2 u;
+            if constexpr (NT_LN_STAGE) u = *(const uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4];   // still there: dx replaces it below
+            else u = ux[mi][nh][ni];
             // opaque copy: otherwise hipcc keeps the first pass's 96 unpacked xhat values alive across the hand-off
             // (common sub-expressions of the two passes) instead of the 48 packed registers, and spills
             asm volatile("" : "+v"(u.x), "+v"(u.y));
@@ -762,7 +833,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
             f32x4 v = q3 == 0 ? dg : q3 == 1 ? db : cs;
             v = f32x4{row16_sum(v[0]), row16_sum(v[1]), row16_sum(v[2]), row16_sum(v[3])};
             if (frow == 0)
-              *(float4*)(p.colpart + ((size_t)(bm * 2 + wm) * 3 + q3) * p.N + bn * TN + nh * 128 + wn * 32 + ni * 16 + fq * 4) =
+              *(float4*)(p.colpart + ((size_t)(bm * 2 + wm) * 3 + q3) * p.N + ncol2 + nh * 128 + ni * 16) =
                   make_float4(v[0], v[1], v[2], v[3]);
           }
         }
