@@ -582,6 +582,9 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     // 32 B, and one dependent round trip per 16-row slab (the plain epilogue's form) cost this epilogue ~10 us per launch
     float rmean[4], rrstd[4];
     uint2 rr[4][NBH][2], ux[4][NBH][2];
+    // (Also measured, not kept: touching the backward form's pre-LayerNorm tile from inside the K loop — one 4-byte load
+    // per 128-byte line, 4 or 8 K-tiles before the end — so that this DMA would find it in L2: the class got slower,
+    // 1.583 -> 1.605 / 1.65 ms per step; loads return in order, so the touches sit in front of the K loop's counted waits.)
     // ---- staged operands (NT_LN_STAGE): one DMA instruction per tile row (TN / 8 active lanes x 16 B = the row's TN
     // bf16), wave w taking rows w, w + 8, ...; destination = the row's place in the output image (row stride OROW), so
     // every lane later finds its 8-byte segments where it will write its results: both passes work IN PLACE.
