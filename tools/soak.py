@@ -24,3 +24,6 @@ print("loss first 5:", np.round(l[:5], 4), "last 5:", np.round(l[-5:], 4), "fini
 assert np.isfinite(l).all() and l[-20:].mean() < l[:20].mean()
 p = tr.engine.params
 print("params finite:", bool(torch.isfinite(p).all().item()), "max |p| %.3f" % float(p.abs().max().item()))
+st = tr.engine.status() if hasattr(tr.engine, "status") else None
+print("in-launch hand-off time-outs (plb_status):", st)
+assert st is None or st["ln_exchange_timeouts"] == 0
