@@ -205,7 +205,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #pragma unroll
         for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
   if constexpr (ACT == 6 && !NT_LN_STAGE) {
-    // LayerNorm-backward form: the residual is the accumulators' START value (its segments arrive under the prologue's
+    // LayerNorm-backward form WITHOUT operand staging (A/B builds): the residual is the accumulators' START value (its segments arrive under the prologue's
     // DMA), not an epilogue operand — beside the kept pre segments it would not fit the epilogue's registers
     if (p.res) {
 #pragma unroll
