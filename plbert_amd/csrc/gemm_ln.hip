@@ -12,6 +12,9 @@ extern "C" int plb_launch_gemm_nt_ln(const PlbGemmNT* p, int mode, hipStream_t s
   if (!p->ln_gamma || !p->ln_mean || !p->ln_rstd || !p->ln_xchg || !p->ln_err || !p->C) return 1;
   if (mode == 5 && (!p->ln_beta || !p->C2)) return 1;
   if (mode == 6 && (!p->aux || !p->colpart)) return 1;
+  // the epilogue's operand tiles arrive by LDS-DMA, 16 bytes per lane: rows must start on 16-byte boundaries
+  if (p->res && (((uintptr_t)p->res & 15) || p->ldr % 8)) return 1;
+  if (mode == 6 && (((uintptr_t)p->aux & 15) || p->ldaux % 8)) return 1;
   dim3 grid((p->M / 128) * (p->N / tile)), block(512);
   const double mnk = (double)p->M * p->N * p->K;
   const double bytes = 2.0 * ((double)p->M * p->K + (double)p->N * p->K) + (double)p->M * p->N * (mode == 5 ? 4 : 4) +

@@ -481,7 +481,14 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #if NT_DBG & 32
   st_[2] = __builtin_amdgcn_s_memrealtime();
 #endif
-  constexpr int OROW = TN + 16;  // image row stride (elements): +32 B rotates the rows over the banks
+  // image row stride (elements): TN + 8, i.e. a row stride of 4 dwords modulo the 64 banks — the 16 rows x 4 lanes of a
+  // half-wave's 8-byte accesses in MFMA layout (ds_write_b64 / ds_read_b64: rows frow, 2 dwords per lane) then cover
+  // the 64 banks exactly once. With TN + 16 (8 dwords modulo 64) rows r and r + 8 met in the same banks: SQ_LDS_BANK_CONFLICT
+  // 1.6e8 cycles per step over the NT kernels, none in the token-major kernel that has no such image (profiles/r03_sq_counters.csv).
+#ifndef NT_OROW_PAD
+#define NT_OROW_PAD 8
+#endif
+  constexpr int OROW = TN + NT_OROW_PAD;
   static_assert(TM * OROW <= RING * HT, "output image must fit the ring");
   f32x4 csum[NBH][2];  // column sums of this wave's rows (only when p.colpart is set)
   float4 bz[NBH][2];

@@ -137,6 +137,13 @@ def test_unsupported_shapes_are_refused():
     p = t.params()
     p.M = 896                                                                # not a multiple of 1024: no fused form
     assert L.plb_launch_gemm_nt_ln(C.byref(p), 5, stream()) == 3
+    p.M = 1024                                                               # operand rows off 16-byte boundaries: refused
+    pre, y = torch.zeros(1024, 768, dtype=torch.bfloat16, device=DEV), torch.zeros(1024, 768, dtype=torch.bfloat16, device=DEV)
+    p.bias, p.C, p.ldc, p.C2, p.ldc2 = t.bias.data_ptr(), pre.data_ptr(), 768, y.data_ptr(), 768
+    p.res, p.ldr = t.res.data_ptr() + 2, 768
+    assert L.plb_launch_gemm_nt_ln(C.byref(p), 5, stream()) == 1
+    p.res, p.ldr = t.res.data_ptr(), 772
+    assert L.plb_launch_gemm_nt_ln(C.byref(p), 5, stream()) == 1
 
 
 def lane_stash_to_rows(blob, M, N):
