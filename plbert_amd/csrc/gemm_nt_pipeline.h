@@ -589,6 +589,10 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     // 32 B, and one dependent round trip per 16-row slab (the plain epilogue's form) cost this epilogue ~10 us per launch
     float rmean[4], rrstd[4];
     uint2 rr[4][NBH][2], ux[4][NBH][2];
+    // (Also measured, not kept: the forward form's residual tile appended to the K loop's own half-tile stream — 6 slabs in
+    // the half-tile image geometry, issued in the ISSUE slots that have run out of A / B half-tiles, counted by the same
+    // vmcnt waits, read out of the ring into registers by conflict-free 8-byte reads. First pass 7.6 -> 4.1 us, K loop
+    // + 1.6 ... 2.2 us; in the step 1.160 -> 1.150 ms for the class, 9.649 vs 9.653 ms per step: nothing.)
     // (Also measured, not kept: touching the backward form's pre-LayerNorm tile from inside the K loop — one 4-byte load
     // per 128-byte line, 4 or 8 K-tiles before the end — so that this DMA would find it in L2: the class got slower,
     // 1.583 -> 1.605 / 1.65 ms per step; loads return in order, so the touches sit in front of the K loop's counted waits.)
