@@ -119,6 +119,45 @@ def test_gemm_layernorm_backward(M, N, K):
 
 
 @pytest.mark.parametrize("mode", [5, 6])
+def test_rows_past_mstore_are_computed_but_never_stored(mode):
+    """Mstore < M (the engine's padded token rows): every output row below Mstore equals the full launch's, every row at or
+    above it keeps its sentinel — images, statistics and the lane-private operand staging must not leak past the bound."""
+    L = _lib.lib()
+    M, N, K, ms = 2048, 768, 768, 2048 - 300
+    t = Ln(M, N, K, seed=11)
+    full = _fwd(t)[0] if mode == 5 else _bwd(t)[1][0]
+    p = t.params()
+    p.Mstore = ms
+    if mode == 5:
+        pre = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        y = torch.full_like(pre, 7.0)
+        t.mean.fill_(7.0); t.rstd.fill_(7.0)
+        p.bias, p.res, p.ldr = t.bias.data_ptr(), t.res.data_ptr(), N
+        p.C, p.ldc, p.C2, p.ldc2 = pre.data_ptr(), N, y.data_ptr(), N
+        assert L.plb_launch_gemm_nt_ln(C.byref(p), 5, stream()) == 0
+        torch.cuda.synchronize()
+        outs = (pre, y, t.mean.clone(), t.rstd.clone())
+        for o, f in zip(outs, full):
+            assert torch.equal(o[:ms], f[:ms]) and bool((o[ms:] == 7.0).all())
+    else:
+        aux = randbf(M, N, seed=77)
+        x = aux.float()
+        t.mean.copy_(x.mean(1)); t.rstd.copy_((x.var(1, unbiased=False) + 1e-12).rsqrt())
+        dx = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        colp = torch.zeros(2 * M // 128, 3, N, dtype=torch.float32, device=DEV)
+        p.res, p.ldr, p.aux, p.ldaux = t.res.data_ptr(), N, aux.data_ptr(), N
+        p.C, p.ldc, p.colpart = dx.data_ptr(), N, colp.data_ptr()
+        assert L.plb_launch_gemm_nt_ln(C.byref(p), 6, stream()) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(dx[:ms], full[0][:ms]) and bool((dx[ms:] == 7.0).all())
+        # whole 128-row tiles below the bound leave the same partial rows; the column sums of dx count stored rows only
+        nt = ms // 128
+        assert torch.equal(colp[: 2 * nt], full[1][: 2 * nt])
+        assert rel_l2(colp[:, 2].double().sum(0), dx[:ms].double().sum(0)) < 1e-5
+    assert int(t.err.item()) == 0 and int(t.xchg.abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("mode", [5, 6])
 def test_hand_off_race_screen(mode):
     """The partner tiles' partials cross CUs (possibly XCDs) inside the launch: 60 launches over the SAME buffers — the
     consumers' caches hold the previous launch's lines — must agree bit for bit, at a shape with 2 and one with 4 column
