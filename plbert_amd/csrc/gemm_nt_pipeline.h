@@ -840,7 +840,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
           *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = o;
           if (ACT == 6 && bm * TM + lrow < p.Mstore) cs += f32x4{bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};
         }
-        if constexpr (ACT == 6) {
+        if constexpr (ACT == 6 && !(NT_DBG & 64)) {   // (NT_DBG 64: timing build without these outputs)
           // dgamma | dbeta | column sums of dx over this wave's 64 rows: one partial row per (row tile, wm)
 #pragma unroll
           for (int q3 = 0; q3 < 3; ++q3) {

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Timing-experiment builds of the NT pipeline GEMM: libplbert_dbgN.so = the product library with
 # gemm_big.hip compiled -DNT_DBG=N (bit mask: 1 no MFMA, 2 no fragment reads, 4 no DMA after the prologue,
-# 8 no K-loop barriers, 16 print the K loop's clock, 32 print phase stamps: tools/nt_stamps.py). Run after the normal build; use with PLBERT_HIP_LIB=... tools/gemm_bench.py.
+# 8 no K-loop barriers, 16 print the K loop's clock, 32 print phase stamps: tools/nt_stamps.py, 64 LayerNorm-backward form without its dgamma / dbeta / bias partial outputs: they cost 3.3 us of a launch). Run after the normal build; use with PLBERT_HIP_LIB=... tools/gemm_bench.py.
 set -e
 cd "$(dirname "$0")/.."
 P=plbert_amd
