@@ -602,7 +602,15 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     // R2 (behind the tables): 64 rows, for the residual of form 6 in two halves — rows of mi 0,1 then rows of mi 2,3 —
     // the second half travelling under the first half's arithmetic.
     constexpr int R2OFF = IMG + 128 * 4 * 2 * 4 + 128 * 2 * 4;   // bytes
-    static_assert(R2OFF + 64 * OROW * 2 <= RING * HT * 2, "staging regions must fit the LDS");
+    constexpr int GAMOFF = R2OFF + 64 * OROW * 2;                 // this tile's TN gamma values (form 6), fp32
+    static_assert(GAMOFF + (ACT == 6 ? TN * 4 : 0) <= RING * HT * 2, "staging regions must fit the LDS");
+    // form 6 reads gamma per 4-column group inside both passes, and those passes are pinned group by group (registers):
+    // from global memory every group waited out an L2 round trip; the tile's gamma row is fetched once, here, beside the
+    // operand tiles' DMA
+    float* const gam_lds = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + GAMOFF);
+    if constexpr (ACT == 6 && NT_LN_STAGE) {
+      if (tid < TN / 4) reinterpret_cast<float4*>(gam_lds)[tid] = *(const float4*)(p.ln_gamma + bn * TN + tid * 4);
+    }
     bf16_t* const r2 = reinterpret_cast<bf16_t*>(reinterpret_cast<char*>(smem) + R2OFF);
     const uint32_t stg_voff = (uint32_t)lane * 16u;
     auto stage_rows = [&](const bf16_t* src, int ld, int nrows, uint32_t lds_base, int half) {
@@ -665,7 +673,8 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         if constexpr (ACT == 6 && NT_LN_STAGE) PIN();   // one column group at a time: hoisting every group's LDS reads to the top spilled
-        const float4 gz = *(const float4*)(p.ln_gamma + ncol0 + nh * 128 + ni * 16);
+        const float4 gz = (ACT == 6 && NT_LN_STAGE) ? *(const float4*)(gam_lds + (ncol0 - bn * TN) + nh * 128 + ni * 16)
+                                                    : *(const float4*)(p.ln_gamma + ncol0 + nh * 128 + ni * 16);
 #pragma unroll
         for (int mi = ((ACT == 6 && NT_LN_STAGE) ? hf * 2 : 0); mi < ((ACT == 6 && NT_LN_STAGE) ? hf * 2 + 2 : 4); ++mi) {
           const int lrow = wm * 64 + mi * 16 + frow;
@@ -812,7 +821,8 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       for (int ni = 0; ni < 2; ++ni) {
         if constexpr (ACT == 6 && NT_LN_STAGE) PIN();
         float4 bt = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 gz = *(const float4*)(p.ln_gamma + ncol2 + nh * 128 + ni * 16);
+        const float4 gz = (ACT == 6 && NT_LN_STAGE) ? *(const float4*)(gam_lds + (ncol2 - bn * TN) + nh * 128 + ni * 16)
+                                                    : *(const float4*)(p.ln_gamma + ncol2 + nh * 128 + ni * 16);
         if constexpr (ACT == 5) bt = *(const float4*)(p.ln_beta + ncol2 + nh * 128 + ni * 16);
         f32x4 cs = {0.f, 0.f, 0.f, 0.f}, dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
