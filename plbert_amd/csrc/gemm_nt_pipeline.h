@@ -895,7 +895,8 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   // form 8 reads it back as full 1-KiB wave accesses. Row-major, a lane's 8-byte segments were 16 partial lines per load
   // instruction: 8.0 us of form 8's epilogue against 2.7 us of arithmetic (tools/nt_stamps.py).
   uint4* const lane_stash = reinterpret_cast<uint4*>(ACT == 7 ? p.C : const_cast<bf16_t*>(p.aux));
-  uint4 sq[3][NBH];            // ACT == 8: stash items in flight
+  constexpr int SQD = 3;       // stash slabs requested ahead (ring of SQD + 1)
+  uint4 sq[SQD + 1][NBH];      // ACT == 8: stash items in flight
   uint2 keep[NAH][4][NBH][2];  // ACT == 1: the packed pre-activations, for the second (gelu) image
   // FP8 with p.C8: the fp8 copy of the output (act 1: of gelu) that the next fp8 GEMM reads, packed 4 values per
   // register here and written through the LDS image as bytes after the bf16 outputs have left; amax of the launch
@@ -926,24 +927,24 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       }
       if (ACT == 8) {
         // the stash of form 7 in LANE layout (see there): this lane's 16 bytes of slab (mh, mi), column half nh — requested
-        // two slabs ahead (a ring of three): taken slab by slab, each of the 8 slabs of a tile cost one memory round trip
+        // SQD slabs ahead: taken slab by slab, each of the 8 slabs of a tile cost one memory round trip
         constexpr int NS = NAH * 4;
         const int sl = mh * 4 + mi;
         if (sl == 0) {
 #pragma unroll
-          for (int a = 0; a < 2 && a < NS; ++a)
+          for (int a = 0; a < SQD && a < NS; ++a)
 #pragma unroll
             for (int nh = 0; nh < NBH; ++nh)
               sq[a][nh] = lane_stash[((size_t)(bm * nbn + bn) * (NS * NBH) + a * NBH + nh) * 512 + tid];
         }
-        if (sl + 2 < NS) {
+        if (sl + SQD < NS) {
 #pragma unroll
           for (int nh = 0; nh < NBH; ++nh)
-            sq[(sl + 2) % 3][nh] = lane_stash[((size_t)(bm * nbn + bn) * (NS * NBH) + (sl + 2) * NBH + nh) * 512 + tid];
+            sq[(sl + SQD) % (SQD + 1)][nh] = lane_stash[((size_t)(bm * nbn + bn) * (NS * NBH) + (sl + SQD) * NBH + nh) * 512 + tid];
         }
 #pragma unroll
         for (int nh = 0; nh < NBH; ++nh) {
-          const uint4 q = sq[sl % 3][nh];
+          const uint4 q = sq[sl % (SQD + 1)][nh];
           ux[nh][0] = make_uint2(q.x, q.y); ux[nh][1] = make_uint2(q.z, q.w);
         }
       }
