@@ -51,8 +51,9 @@ def flop_per_token_step(cfg, seq, num_phonemes, num_tokens=0):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    # 100 timed steps = ~1 s: a single burst of box noise (a clock excursion, a host hiccup) cannot move the line by 1 %
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -210,7 +211,7 @@ def secondary_lines():
 
     out = {}
     for key, extra in (("large", ["--model", "large"]), ("fp8", ["--dtype", "fp8"])):
-        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "10", "--warmup", "4", "--no-cpu-baseline",
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "8", "--no-cpu-baseline",
                "--no-traffic", "--no-staged", "--no-secondary", *extra]
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240, text=True)
@@ -525,6 +526,8 @@ def main():
         k = 1e3 / args.steps
         comm_info.update(step_ms_overlap=round(t_ov * k, 3), step_ms_serial=round(t_se * k, 3),
                          step_ms_no_exchange=round(t_nc * k, 3),
+                         # what the exchange costs the step in the form that hides it: the first thing to read in an N > 1 line
+                         exposed_ms=round((t_ov - t_nc) * k, 3),
                          allreduce_ms_per_step_exposed=round((min(t_ov, t_se) - t_nc) * k, 3))
         trainer.comm = "none"
         trainer.reducer.active = False

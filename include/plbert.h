@@ -177,11 +177,23 @@ int plb_comm_unique_id(uint8_t id[PLB_COMM_ID_BYTES]);
 int plb_comm_init(PlbEngine* e, const uint8_t id[PLB_COMM_ID_BYTES], int32_t rank, int32_t world);
 int plb_comm_destroy(PlbEngine* e);
 int plb_comm_info(const PlbEngine* e, int32_t* rank, int32_t* world, int32_t* rccl_version);
-/* Diagnostic, SYNCHRONISES the device: hand-offs between the column tiles of the LayerNorm-in-GEMM launches (csrc/
- * gemm_ln.hip) that timed out since the engine was bound. Must be 0: a non-zero count means a launch's tiles were not
- * co-resident long enough and its LayerNorm statistics are invalid (the wait is bounded so that such a launch ends
- * instead of hanging the device). No reference counterpart (the reference's LayerNorm is torch's kernel). */
+/* Health of the in-launch hand-offs between the column tiles of the LayerNorm-in-GEMM launches (csrc/gemm_ln.hip). Their
+ * wait is bounded so that a launch whose tiles were not co-resident long enough ENDS instead of hanging the device; the
+ * launch then raises the engine's error word, and by construction (no host round trip anywhere):
+ *   - the loss that call returns is NaN, and the word is mirrored into pinned host memory by the call's last launch;
+ *   - plb_adamw_step leaves parameters, moments and compute copies untouched while the word is set;
+ *   - the word stays set — every later step is skipped the same way — until plb_status has reported it.
+ * plb_poll_status: NO synchronisation; the count as of the last loss call that has COMPLETED on the device (read it
+ *   wherever the host has just read a loss back, or one step late at the top of the next step).
+ * plb_status / plb_status_ex: SYNCHRONISES the device and returns the count since its previous report; a non-zero report also re-zeroes
+ *   the exchange buffer and the word (a producer's store that landed after its consumer gave up would otherwise look
+ *   fresh to the next launch), so the step after a reported failure starts clean. 0 in every run so far.
+ * No reference counterpart (the reference's LayerNorm is torch's kernel); the Python host raises HandoffTimeout. */
 int plb_status(PlbEngine* e, int32_t* ln_exchange_timeouts);
+/* plb_status + the number of plb_adamw_step calls the device left out since the word was raised (a host that counts
+ * optimizer steps for the bias correction rewinds its count by it); either pointer may be NULL. */
+int plb_status_ex(PlbEngine* e, int32_t* ln_exchange_timeouts, int32_t* skipped_updates);
+int plb_poll_status(const PlbEngine* e, int32_t* ln_exchange_timeouts);
 /* What the last training step exchanged: the number of collectives it issued (8 pieces for the reference's phoneme-only
  * step with overlap on, 1 with overlap off; one more after a dual-head step) and the floats they covered. The reference
  * has no counterpart (DDP's bucket count is internal to torch, train.py:218-221); a caller logs it to see which form of
@@ -240,6 +252,21 @@ void plb_profile_enable(int on);
 int plb_profile_num_classes(void);
 const char* plb_profile_class_name(int cls);
 int plb_profile_read(double* ms, int64_t* launches, double* flops, double* bytes);
+
+/* ---- test and tuning hooks (exported by the same library; NOT part of the drop-in surface, no reference counterpart).
+ * They change process-wide state of the launchers and exist for tests/ and tools/ only:
+ *   plb_debug_skip_piece(i)       the next loss call leaves out its i-th all-reduce piece, as a forgotten tensor would;
+ *                                 the call must fail ("gradient exchange covered ..."), tests/test_gpu_comm_fake_rccl.py
+ *   plb_debug_ln_fault(mode, n)   the next n fused LayerNorm launches run with a broken hand-off (1: one column tile
+ *                                 never publishes; 2: consumed granules stay tagged), tests/test_gpu_handoff_fault.py
+ *   plb_set_gemm_nt_tile / plb_set_gemm_nt_prefetch / plb_set_attn_bwd_fused
+ *                                 force a tile, a K-loop form or the attention-backward form for the launches that
+ *                                 follow (0 / -1 / 0 restore the per-shape policy), tests/test_gpu_kernels.py, tools/ */
+void plb_debug_skip_piece(int index);
+void plb_debug_ln_fault(int mode, int launches);
+void plb_set_gemm_nt_tile(int tile);
+void plb_set_gemm_nt_prefetch(int on);
+void plb_set_attn_bwd_fused(int on);
 
 #ifdef __cplusplus
 }

@@ -293,7 +293,17 @@ def capture_dualloss(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, n_s
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "dualloss": regenerate only the (2c) fixtures
+    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "dualloss" / "large": regenerate only those fixtures
+    # (4) BASELINE configs[3]'s architecture (hidden 1024, 24 shared layers, 16 heads, FFN 4096; SURVEY.md section 8:
+    # ALBERT-large's heads / FFN width) at 4 x 256 = 1024 tokens with one ragged row: the token count at which the
+    # engine runs its fused LayerNorm epilogues with FOUR column tiles per row block (H = 1024); probes only
+    large = dict(vocab_size=188, hidden_size=1024, num_attention_heads=16, intermediate_size=4096,
+                 max_position_embeddings=512, num_hidden_layers=24)
+    if only in ("", "large"):
+        capture_model("real_h1024_s256_b4", large, 188, 0, ragged_batch(4, 256, [256, 256, 256, 201], seed=8), seed=24,
+                      full=False, n_steps=2)
+        if only:
+            return
     tiny = dict(vocab_size=188, embedding_size=16, hidden_size=64, num_attention_heads=4,
                 intermediate_size=128, num_hidden_layers=2, max_position_embeddings=512)
     small = dict(vocab_size=188, embedding_size=64, hidden_size=128, num_attention_heads=2,

@@ -54,8 +54,10 @@ PUBLIC_SYMBOLS = [
     "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
     "plb_sync_weights", "plb_forward", "plb_pooler", "plb_loss_fwd_bwd", "plb_loss_fwd", "plb_loss_fwd_bwd_dual", "plb_adamw_step",
     "plb_set_fp8", "plb_fp8_state", "plb_token_head_steps", "plb_set_token_head_steps", "plb_comm_unique_id", "plb_comm_init", "plb_comm_destroy",
-    "plb_comm_info", "plb_comm_pieces", "plb_status", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
+    "plb_comm_info", "plb_comm_pieces", "plb_status", "plb_status_ex", "plb_poll_status", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
     "plb_mask_batch", "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
+    # test / tuning hooks (documented as such at the end of the header)
+    "plb_debug_skip_piece", "plb_debug_ln_fault", "plb_set_gemm_nt_tile", "plb_set_gemm_nt_prefetch", "plb_set_attn_bwd_fused",
 ]
 
 
@@ -82,7 +84,7 @@ class PlbGemmNT(C.Structure):
         ("deq_a", C.c_void_p), ("deq_b", C.c_void_p), ("C8", C.c_void_p), ("ldc8", C.c_int), ("q_scale", C.c_void_p),
         ("q_amax", C.c_void_p), ("c8_bf8", C.c_int),
         ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_mean", C.c_void_p), ("ln_rstd", C.c_void_p),
-        ("ln_eps", C.c_float), ("ln_xchg", C.c_void_p), ("ln_err", C.c_void_p),
+        ("ln_eps", C.c_float), ("ln_xchg", C.c_void_p), ("ln_err", C.c_void_p), ("ln_fault", C.c_int),
     ]
 
 
@@ -187,6 +189,14 @@ def lib():
     L.plb_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.plb_status.restype = C.c_int
     L.plb_status.argtypes = [vp, C.POINTER(i32)]
+    L.plb_status_ex.restype = C.c_int
+    L.plb_status_ex.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.plb_poll_status.restype = C.c_int
+    L.plb_poll_status.argtypes = [vp, C.POINTER(i32)]
+    L.plb_debug_ln_fault.restype = None
+    L.plb_debug_ln_fault.argtypes = [C.c_int, C.c_int]
+    L.plb_debug_skip_piece.restype = None
+    L.plb_debug_skip_piece.argtypes = [C.c_int]
     L.plb_comm_pieces.restype = C.c_int
     L.plb_comm_pieces.argtypes = [vp, C.POINTER(i32), C.POINTER(C.c_int64)]
     L.plb_broadcast_params.restype = C.c_int

@@ -33,6 +33,76 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+def disassemble_code_objects(lib, workdir):
+    """(path, disassembly) of every gfx950 code object in ``lib`` (llvm-objdump ships with ROCm; --offloading writes the
+    bundles next to its input, so it runs on a copy under ``workdir``)."""
+    import glob
+    import shutil
+    cp = shutil.copy(lib, workdir)
+    subprocess.run([OBJDUMP, "--offloading", cp], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    cos = sorted(glob.glob(cp + ".*gfx950"))
+    if not cos:
+        raise RuntimeError("no gfx950 code object extracted from " + lib)
+    for co in cos:
+        yield co, subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", co], check=True, stdout=subprocess.PIPE,
+                                 text=True).stdout
+
+
+def verify_m0(lib=LIB, workdir=None):
+    """Post-link check of EVERY build (also run by tests/test_cabi_and_host.py). The LDS-DMA statements (csrc/common.h:
+    DMA16 / DMA4) write M0 and consume it inside one asm statement (`s_mov_b32 m0, sN; s_nop 0; global_load_lds_*`) and
+    cannot usefully declare the clobber: hipcc reserves M0, ignores an "m0" clobber and only warns about it. That is safe
+    exactly while no COMPILER-generated instruction keeps a value in M0 across such a statement, which depends on the
+    hipcc version and on what else a kernel uses (builtin LDS-DMA, s_movrel, ...). So the disassembly is checked, kernel
+    by kernel: a kernel that contains the statement's signature must contain NO other use of M0 — every write of M0 is
+    the signature's, every LDS-DMA is the signature's, nothing reads M0; kernels whose DMAs are all the builtin's
+    (csrc/gemm.hip) leave M0 to the compiler and are only required never to read it. Returns the number of asm DMA
+    statements seen; raises RuntimeError on a violation; returns None when llvm-objdump is absent."""
+    import re
+    import tempfile
+    if not os.path.exists(OBJDUMP):
+        return None
+    own = workdir is None
+    tmp = tempfile.mkdtemp(prefix="plbert_m0_") if own else workdir
+    n_asm = 0
+    try:
+        for co, text in disassemble_code_objects(lib, tmp):
+            funcs, cur = {}, None
+            for ln in text.splitlines():
+                i = ln.split("//")[0].strip()
+                m = re.match(r"^[0-9a-f]+ <(.+)>:$", i)
+                if m:
+                    cur = funcs.setdefault(m.group(1), [])
+                elif cur is not None and i and not i.endswith(":"):
+                    cur.append(i)
+            for name, ins in funcs.items():
+                def dma(i):
+                    return i.startswith("global_load_lds") or (i.startswith("buffer_load") and i.rstrip().endswith("lds"))
+                sig = [k for k in range(len(ins) - 2) if re.match(r"s_mov_b32 m0, s\d+$", ins[k]) and ins[k + 1] == "s_nop 0"
+                       and dma(ins[k + 2]) and " s[" in ins[k + 2]]  # scalar-base form: only the asm statements use it
+                for i in ins:
+                    if re.match(r"(s_movrel|v_movrel|ds_gws|ds_ordered|s_sendmsg|v_interp)", i):
+                        raise RuntimeError(f"M0 check: {name}: instruction that reads M0: {i}")
+                    if re.search(r"\bm0\b", i):  # M0 only ever as the destination of a scalar instruction
+                        if not (re.match(r"s_\w+ m0, ", i) and not re.search(r"\bm0\b", i.split(",", 1)[1])):
+                            raise RuntimeError(f"M0 check: {name}: M0 used as a source: {i}")
+                if not sig:
+                    continue
+                n_asm += len(sig)
+                owned = set(sig) | {k + 2 for k in sig}
+                for k, i in enumerate(ins):
+                    if (dma(i) or re.search(r"\bm0\b", i)) and k not in owned:
+                        raise RuntimeError(f"M0 check: {name}: M0 / LDS-DMA outside the asm DMA statements: {ins[max(0, k - 2):k + 3]}")
+    finally:
+        if own:
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+    return n_asm
+
+
 def build(force=False, verbose=True):
     """Compile every HIP source for gfx950 and link the C-ABI shared library next to the package."""
     if not force and not needs_build():
@@ -57,6 +127,11 @@ def build(force=False, verbose=True):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout)
+    try:
+        verify_m0(LIB)   # a user build with another hipcc must not ship kernels in which the compiler uses M0 around the DMAs
+    except Exception:
+        os.remove(LIB)
+        raise
     return LIB
 
 

@@ -108,8 +108,8 @@ DEVI s16x4 lds_read_tr16_addr(uint32_t lds_byte_addr) {
 // M0 = LDS byte address of the 1-KiB (256-B for the dword form) destination; one wait state after writing M0.
 // M0 is written and read inside ONE statement and is not on the clobber list: hipcc reserves M0 and ignores such a
 // clobber (it only draws -Winline-asm). What makes this safe is that no compiler-generated instruction of these kernels
-// reads M0 — tests/test_cabi_and_host.py::test_m0_is_only_touched_by_the_dma_statements checks the disassembly of every
-// code object of the library for exactly that.
+// reads M0 — plbert_amd/build.py: verify_m0 checks the disassembly of every code object for exactly that as a POST-LINK
+// step of every build (a violating library is deleted, the build fails), and tests/test_cabi_and_host.py runs it again.
 typedef __attribute__((address_space(3))) char lds_char;
 #define LDS_ADDR(ptr) ((uint32_t)(uintptr_t)(lds_char*)(ptr))
 #define DMA16(sbase, voff, ldsaddr) \

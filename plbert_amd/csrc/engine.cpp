@@ -179,7 +179,11 @@ struct PlbEngine {
   int part_rows = 0;            // rows per layer reserved in o_part1 / o_part2
   int part_rows_used = 0;       // rows per layer the last backward wrote
   int ln_fuse = 3;              // bit 0: LayerNorm forward in the producing GEMM's epilogue, bit 1: LayerNorm backward
-  int64_t o_lnx = 0, o_lnerr = 0;
+  int64_t o_lnx = 0, o_lnerr = 0, lnx_bytes = 0;
+  // host-visible mirror of the hand-off error word (pinned, device-mapped): written by the last launch of every loss
+  // call, read by plb_poll_status without synchronising
+  unsigned int* host_err = nullptr;
+  unsigned int* host_err_dev = nullptr;
   bool gelu_dstash_on = true;   // PLBERT_GELU_STASH=u restores the pre-activation stash
   bool u_is_derivative = false; // what the "u" slots hold after the last forward
   // fp8 mode (plb_set_fp8): transient 1-byte images of the fp8 GEMMs' activation / gradient operands, fp8 weight copies
@@ -334,7 +338,8 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   e->o_mean1 = cv.take(Ls * Tp * 4); e->o_rstd1 = cv.take(Ls * Tp * 4);
   e->o_mean2 = cv.take(Ls * Tp * 4); e->o_rstd2 = cv.take(Ls * Tp * 4);
   // exchange granules of the LayerNorm epilogues: [Tp/128][nbn][nbn][128][2] x 8 B, nbn <= 4 column tiles; zero between launches
-  e->o_lnx = cv.take((Tp / 128) * 16 * 128 * 2 * 8);
+  e->lnx_bytes = (Tp / 128) * 16 * 128 * 2 * 8;
+  e->o_lnx = cv.take(e->lnx_bytes);
   e->o_lnerr = cv.take(256);
   if (tr) {
     e->o_delta = cv.take(stat);
@@ -432,6 +437,7 @@ extern "C" void plb_destroy(PlbEngine* e) {
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->side) (void)hipStreamDestroy(e->side);
+  if (e->host_err) (void)hipHostFree(e->host_err);
   delete e;
 }
 
@@ -456,6 +462,20 @@ extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_av
   if ((uintptr_t)workspace & 255) return fail("plb_bind: workspace must be 256-byte aligned");
   e->params = params; e->grads = grads; e->m = exp_avg; e->v = exp_avg_sq;
   e->ws = (char*)workspace;
+  if (!e->host_err) {  // once, outside any launch sequence
+    void* h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess && h) {
+      void* d = nullptr;
+      if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+        e->host_err = (unsigned int*)h;
+        e->host_err_dev = (unsigned int*)d;
+        *e->host_err = 0;
+      } else {
+        (void)hipHostFree(h);
+      }
+    }
+    if (!e->host_err) return fail("plb_bind: cannot allocate the pinned status word");
+  }
   if (!e->side && grads && !getenv("PLBERT_NO_SIDE_STREAM")) {  // created once, outside any launch sequence (a step may be graph-captured)
     // (default priority: at the highest one the step measured the same, 10.20-10.22 ms either way)
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side = nullptr;
@@ -763,6 +783,7 @@ extern "C" int plb_forward(PlbEngine* e, const int64_t* ids, const int32_t* leng
     TRY(fp8_update_scales(e, s));
     e->fp8_ready = true;
   }
+  TRY(plb_launch_step_status(e->at<unsigned int>(e->o_lnerr), nullptr, e->host_err_dev, s));
   return 0;
 }
 
@@ -977,6 +998,7 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       TRY(fp8_update_scales(e, s));
       e->fp8_ready = true;
     }
+    TRY(plb_launch_step_status(e->at<unsigned int>(e->o_lnerr), loss, e->host_err_dev, s));
     return 0;
   }
 
@@ -1085,7 +1107,11 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     e->fp8_ready = true;
     e->fp8_bwd_ready = true;
   }
-  return backward_tail(e, masked_ids, dy, B, S, du_rows, s);
+  if (backward_tail(e, masked_ids, dy, B, S, du_rows, s)) return 1;
+  // Last launch of the step: a hand-off of the fused LayerNorm launches that timed out turns the loss into NaN and shows
+  // in plb_poll_status; plb_adamw_step skips on the same word. Nothing waits for anything.
+  TRY(plb_launch_step_status(e->at<unsigned int>(e->o_lnerr), loss, e->host_err_dev, s));
+  return 0;
 }
 
 // Tail of the backward on two streams.
@@ -1270,12 +1296,29 @@ extern "C" int plb_comm_info(const PlbEngine* e, int32_t* rank, int32_t* world, 
   return 0;
 }
 
-extern "C" int plb_status(PlbEngine* e, int32_t* ln_exchange_timeouts) {
+extern "C" int plb_status_ex(PlbEngine* e, int32_t* ln_exchange_timeouts, int32_t* skipped_updates) {
   if (!e || !e->ws) return fail("plb_status: engine not bound");
-  unsigned int v = 0;
+  unsigned int v[2] = {0, 0};
   HIPTRY(hipDeviceSynchronize());
-  HIPTRY(hipMemcpy(&v, e->at<unsigned int>(e->o_lnerr), sizeof(v), hipMemcpyDeviceToHost));
-  if (ln_exchange_timeouts) *ln_exchange_timeouts = (int32_t)v;
+  HIPTRY(hipMemcpy(v, e->at<unsigned int>(e->o_lnerr), sizeof(v), hipMemcpyDeviceToHost));
+  if (ln_exchange_timeouts) *ln_exchange_timeouts = (int32_t)v[0];
+  if (skipped_updates) *skipped_updates = (int32_t)v[1];
+  if (v[0]) {
+    // Reported once, then gone: a producer whose store landed after its consumer had given up leaves a tagged granule
+    // that the next launch would take for a fresh one, so the exchange buffer is zeroed again (the device is idle
+    // here) together with the error word and its host mirror. The next step starts clean.
+    HIPTRY(hipMemset(e->at<char>(e->o_lnx), 0, (size_t)e->lnx_bytes));
+    HIPTRY(hipMemset(e->at<char>(e->o_lnerr), 0, 256));
+    HIPTRY(hipDeviceSynchronize());
+    if (e->host_err) *(volatile unsigned int*)e->host_err = 0;
+  }
+  return 0;
+}
+extern "C" int plb_status(PlbEngine* e, int32_t* ln_exchange_timeouts) { return plb_status_ex(e, ln_exchange_timeouts, nullptr); }
+
+extern "C" int plb_poll_status(const PlbEngine* e, int32_t* ln_exchange_timeouts) {
+  if (!e || !e->ws || !e->host_err) return fail("plb_poll_status: engine not bound");
+  if (ln_exchange_timeouts) *ln_exchange_timeouts = (int32_t)*(volatile const unsigned int*)e->host_err;
   return 0;
 }
 
@@ -1381,14 +1424,15 @@ extern "C" int plb_adamw_step(PlbEngine* e, double lr, double beta1, double beta
     e->comm_pending = false;
   }
   TRY(plb_launch_adamw(e->params, e->grads, e->m, e->v, e->at<bf16_t>(e->o_wbf), (size_t)e->ptrain, lr, beta1, beta2, eps,
-                       weight_decay, step, grad_scale, s));
+                       weight_decay, step, grad_scale, e->at<unsigned int>(e->o_lnerr), 1, s));
   if (e->tok_grads_live) {
     // token head: trained only by dual-head steps (no gradient, no update — as the pooler), with its OWN step count:
     // torch.optim.AdamW keeps one per parameter, so a head that starts training late gets its own bias correction
     const int64_t o = e->poff[PLB_TOK_W];
     e->tok_steps += 1;
     TRY(plb_launch_adamw(e->params + o, e->grads + o, e->m + o, e->v + o, e->at<bf16_t>(e->o_wbf) + o,
-                         (size_t)(e->ptotal - o), lr, beta1, beta2, eps, weight_decay, e->tok_steps, grad_scale, s));
+                         (size_t)(e->ptotal - o), lr, beta1, beta2, eps, weight_decay, e->tok_steps, grad_scale,
+                         e->at<unsigned int>(e->o_lnerr), 0, s));
   }
   return sync_transposes(e, s);
 }

@@ -4,7 +4,14 @@
 // (backward). A translation unit of its own so that the plain instantiations keep their register allocation.
 #include "gemm_nt_pipeline.h"
 
-extern "C" int plb_launch_gemm_nt_ln(const PlbGemmNT* p, int mode, hipStream_t stream) {
+static int g_ln_fault_mode = 0, g_ln_fault_launches = 0;
+extern "C" void plb_debug_ln_fault(int mode, int launches) { g_ln_fault_mode = mode; g_ln_fault_launches = launches; }
+
+extern "C" int plb_launch_gemm_nt_ln(const PlbGemmNT* p_in, int mode, hipStream_t stream) {
+  PlbGemmNT q_ = *p_in;
+  q_.ln_fault = 0;
+  if (g_ln_fault_launches > 0) { q_.ln_fault = g_ln_fault_mode; --g_ln_fault_launches; }
+  const PlbGemmNT* p = &q_;
   if (mode != 5 && mode != 6) return 1;
   if (p->M % 1024 || p->K % 64 || p->M <= 0 || p->N <= 0 || p->K <= 0) return 3;   // 8 XCDs x whole row blocks
   const int tile = p->N % 384 == 0 ? 384 : p->N % 256 == 0 ? 256 : 0;

@@ -53,6 +53,10 @@ typedef struct {
   float ln_eps;
   unsigned long long* ln_xchg;  // [(M/128)][N/TN producer][N/TN consumer][128 rows][2] tagged granules; zero before and after every launch
   unsigned int* ln_err;         // incremented when a hand-off timed out (results of that launch are then invalid)
+  int ln_fault;                 // fault injection (plb_debug_ln_fault; tests only, 0 in every product launch): 1 = the last
+                                // column tile of every row block does not publish its partials (its partners time out),
+                                // 2 = column tile 0 reports a time-out and leaves the granules it consumed TAGGED (what a
+                                // producer's store landing after the time-out looks like to the next launch)
 } PlbGemmNT;
 // LayerNorm in the epilogue of the GEMM that produces its input (big-tile kernels with 128-row tiles; M % 1024 == 0,
 // N % 384 == 0 or N % 256 == 0):
@@ -174,6 +178,10 @@ int plb_launch_attn_bwd_fused(const PlbAttn* p, hipStream_t stream);
 // all-reduce piece, as a forgotten tensor would; the call must then fail in pieces_done() instead of training on a
 // gradient range that was never exchanged.
 void plb_debug_skip_piece(int index);
+// Test hook of the LayerNorm hand-off (tests/test_gpu_handoff_fault.py): the next `launches` fused LayerNorm launches run
+// with PlbGemmNT.ln_fault = mode (see there). The step they belong to must be reported (plb_poll_status / plb_status),
+// must not reach the parameters (the AdamW launch skips) and must leave nothing behind once plb_status has reported it.
+void plb_debug_ln_fault(int mode, int launches);
 void plb_set_attn_bwd_fused(int on);
 
 // Loss rows: row r of the gathered matrix is token rows[r]
@@ -218,8 +226,15 @@ typedef struct {
 int plb_launch_apply_mask(const PlbApplyMask* p, hipStream_t stream);
 
 // AdamW (torch.optim.AdamW semantics) over a flat range; also refreshes the bf16 compute copy.
+// skip_if_nonzero (two device words, or null): the launch leaves everything untouched when word 0 is non-zero — the engine's
+// hand-off error word, so that a step whose LayerNorm statistics are invalid never reaches the parameters (no host round
+// trip); with count_skip the launch then adds 1 to word 1 (optimizer steps left out)
 int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, double lr, double beta1,
-                     double beta2, double eps, double wd, int step, double grad_scale, hipStream_t stream);
+                     double beta2, double eps, double wd, int step, double grad_scale, unsigned int* skip_if_nonzero,
+                     int count_skip, hipStream_t stream);
+// End of a loss call: mirror the hand-off error word into host-visible memory (host_mirror: device pointer of a pinned
+// host word) and, when it is non-zero, overwrite the loss with NaN — whoever reads the loss sees that the step is invalid
+int plb_launch_step_status(const unsigned int* ln_err, float* loss, unsigned int* host_mirror, hipStream_t stream);
 int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream);
 // dst[c, r] = bf16(src[r, c]) for r<R, c<C ; dst has ldd >= R columns (zero fill is the caller's job)
 int plb_launch_transpose_cast(const float* src, int R, int C, bf16_t* dst, int ldd, hipStream_t stream);

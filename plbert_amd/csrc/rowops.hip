@@ -795,9 +795,16 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* x, int n, fl
 //   p *= 1 - lr*wd;  m = lerp(m, g, 1-b1);  v = b2*v + (1-b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 // The scalars are formed on the host in DOUBLE and rounded once, as torch forms them in Python floats: 1.0f - 0.999f
 // is 0.99998713e-3, not 1e-3f — a 1.3e-5 relative error in every second moment (tests/test_gpu_adamw_kernel.py).
+// skip: the engine's hand-off error word (or null). Non-zero = a fused LayerNorm launch of this step timed out: its
+// gradients are invalid and the whole update is left out (a uniform scalar load and branch; the host learns of it from
+// plb_poll_status / plb_status without this launch having waited for anybody).
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* pb, size_t n,
                                                     float decay, float omb1, float b2, float omb2, float eps, float step,
-                                                    float bc2_sqrt, float gscale) {
+                                                    float bc2_sqrt, float gscale, unsigned int* skip, int count_skip) {
+  if (skip && *skip) {   // skip[1] counts the optimizer steps left out (the host rewinds its step count by it)
+    if (count_skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1u);
+    return;
+  }
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i >= n) return;  // n is a multiple of 4 (checked by the launcher)
   float4 P = *(const float4*)(p + i), G = *(const float4*)(g + i), M = *(const float4*)(m + i), V = *(const float4*)(v + i);
@@ -815,6 +822,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
   *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
   *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
   if (pb) { uint2 o; o.x = pack_bf2(pp[0], pp[1]); o.y = pack_bf2(pp[2], pp[3]); *(uint2*)(pb + i) = o; }
+}
+// one thread, at the end of a loss call (plb_launch_step_status)
+__global__ void step_status_kernel(const unsigned int* ln_err, float* loss, unsigned int* host_mirror) {
+  const unsigned int e = *ln_err;
+  if (host_mirror) __hip_atomic_store(host_mirror, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (e && loss) *loss = __builtin_nanf("");
 }
 __global__ void cast_bf16_kernel(const float* src, bf16_t* dst, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1071,14 +1084,18 @@ extern "C" int plb_launch_sum_rows(const float* x, int n, float* out, hipStream_
 }
 extern "C" int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, double lr,
                                 double beta1, double beta2, double eps, double wd, int step, double grad_scale,
-                                hipStream_t stream) {
+                                unsigned int* skip_if_nonzero, int count_skip, hipStream_t stream) {
   if (n % 4 || step < 1) return 1;
   if (!n) return 0;
   ProfScope ps(PLB_K_ADAMW, stream, 0, (double)n * 30.0);  // p,m,v read+write, g read, bf16 copy
   const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, p, g, m, v, p_bf16, n,
                      (float)(1.0 - lr * wd), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
-                     (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale);
+                     (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale, skip_if_nonzero, count_skip);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_step_status(const unsigned int* ln_err, float* loss, unsigned int* host_mirror, hipStream_t stream) {
+  hipLaunchKernelGGL(step_status_kernel, dim3(1), dim3(1), 0, stream, ln_err, loss, host_mirror);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream) {

@@ -9,6 +9,7 @@ local count of non-empty samples, gradients are averaged, parameters are broadca
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -41,14 +42,31 @@ def init_from_env():
     return rank, dist.get_world_size(), device
 
 
-def shard_batch(batch, rank, world, pad=False):
-    """accelerate BatchSamplerShard(split_batches=True): contiguous equal slices of the collated batch.
-    ``batch`` = (labels [B,S], masked [B,S], lengths list, masked_indices list).
-    ``pad``: a batch whose size is not a multiple of the world size (the last batch of a ``drop_last=False`` loader,
-    i.e. validation) is completed with its own first samples, as accelerate's ``even_batches=True`` does."""
+def shard_batch(batch, rank, world, pad=False, batch_size=None, first_batch=None):
+    """accelerate BatchSamplerShard(split_batches=True) (ACC:data_loader.py, the reference's train.py:220): contiguous equal
+    slices of the collated batch. ``batch`` = (labels [B,S], masked [B,S], lengths list, masked_indices list).
+    ``pad``: what happens to a SHORT batch (the last one of a ``drop_last=False`` loader, i.e. validation):
+      * with ``batch_size`` and ``first_batch`` (the pass's first collated batch, same 4-tuple): accelerate's
+        ``even_batches=True`` — the short batch is completed to the full ``batch_size`` with the samples of the pass's
+        first batch, in order (cycled if needed), and every rank takes ``batch_size // world`` of it. Rows of the two
+        batches may have different padded widths (each is padded to its own longest sample): the narrower is zero-padded;
+      * without them: completed only up to the next multiple of ``world`` with its OWN first samples — a deliberate
+        simplification for callers that have no pass context (per-rank sample count and content of that one batch then
+        differ from accelerate's; the training batches, which are always full, are unaffected)."""
     labels, masked, lengths, idx = batch
     B = len(lengths)
-    if B % world and pad:
+    if pad and batch_size is not None and first_batch is not None and B < batch_size:
+        fl, fm, flen, fidx = first_batch
+        nf = len(flen)
+        take = [i % nf for i in range(batch_size - B)]
+        S = max(labels.shape[1], fl.shape[1])
+        widen = lambda a: np.pad(a, ((0, 0), (0, S - a.shape[1])))
+        labels = np.concatenate([widen(np.asarray(labels)), widen(np.asarray(fl))[take]])
+        masked = np.concatenate([widen(np.asarray(masked)), widen(np.asarray(fm))[take]])
+        lengths = list(lengths) + [flen[i] for i in take]
+        idx = list(idx) + [fidx[i] for i in take]
+        B = batch_size
+    elif B % world and pad:
         extra = [i % B for i in range(world - B % world)]
         take = list(range(B)) + extra
         labels, masked = labels[take], masked[take]

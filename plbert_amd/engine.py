@@ -17,6 +17,12 @@ from . import _lib
 from .init import param_shapes
 
 
+class HandoffTimeout(RuntimeError):
+    """A fused LayerNorm launch's in-launch hand-off timed out (include/plbert.h: plb_status): the step it belongs to is
+    invalid. By the time this is raised the engine has skipped that step's optimizer update and has been reset
+    (exchange buffer and error word zeroed): the caller may simply run the step again."""
+
+
 class HipEngine:
     def __init__(self, cfg, num_phonemes, num_tokens=0, max_batch=32, max_seq=512, device=None, train=True):
         """``train=False``: inference / validation engine (README.md:91, train.py:288-304) — no gradient, moment or
@@ -68,6 +74,7 @@ class HipEngine:
         self._bound = False
         self._synced_version = -1
         self.comm_world = 1
+        self._on_handoff_timeout = []   # callbacks(err): owners of an optimizer step count rewind it by err.skipped_updates
 
     def _bind(self):
         if self._bound:
@@ -180,11 +187,34 @@ class HipEngine:
         return int(r.value), int(w.value), int(v.value)
 
     def status(self):
-        """{'ln_exchange_timeouts': n} — synchronises the device (plb_status)."""
-        n = C.c_int32()
+        """{'ln_exchange_timeouts': n} — synchronises the device (plb_status); a non-zero report resets the exchange
+        state, so it is reported once."""
+        n, k = C.c_int32(), C.c_int32()
         with torch.cuda.device(self.device):
-            _lib.check(self.L.plb_status(self.handle, C.byref(n)), "plb_status")
+            _lib.check(self.L.plb_status_ex(self.handle, C.byref(n), C.byref(k)), "plb_status_ex")
+        return {"ln_exchange_timeouts": int(n.value), "skipped_updates": int(k.value)}
+
+    def poll_status(self):
+        """The same count WITHOUT synchronising: as of the last loss call that has completed on the device."""
+        if not self._bound:
+            return {"ln_exchange_timeouts": 0}
+        n = C.c_int32()
+        _lib.check(self.L.plb_poll_status(self.handle, C.byref(n)), "plb_poll_status")
         return {"ln_exchange_timeouts": int(n.value)}
+
+    def raise_if_failed(self):
+        """Raise HandoffTimeout if a completed step reported a timed-out hand-off. Costs one read of a pinned host
+        word: called at the top of every training step (one step late at worst — the device has already left the
+        failed step's update out) and wherever a loss has just been read back (exact)."""
+        if self.poll_status()["ln_exchange_timeouts"]:
+            st = self.status()   # synchronises, reports once and resets the exchange state
+            err = HandoffTimeout(f"{st['ln_exchange_timeouts']} in-launch LayerNorm hand-off(s) timed out: the loss of "
+                                 f"that step is NaN and {st['skipped_updates']} optimizer update(s) were skipped on the "
+                                 "device; the engine has been reset, re-run the step")
+            err.skipped_updates = st["skipped_updates"]
+            for fn in self._on_handoff_timeout:
+                fn(err)
+            raise err
 
     def comm_pieces(self):
         """(collectives, floats) of the last step's gradient exchange."""
@@ -285,6 +315,7 @@ class HipEngine:
     def _loss_call(self, backward, masked_ids, labels, lengths, idx_offsets, idx_flat, n_masked, token_ids):
         if backward and not self.train_mode:
             raise RuntimeError("this HipEngine was built with train=False (inference / validation only)")
+        self.raise_if_failed()   # a step that completed since the last call and timed out: never train on top of it
         self._ensure_synced()
         masked_ids = self._dev_i64(masked_ids)
         labels = self._dev_i64(labels)

@@ -79,6 +79,13 @@ class DeviceFeeder:
         for _ in range(int(n)):
             self._budget.release()
 
+    def reset_budget(self, n=0):
+        """Forget permits a previous loop left unused (it returned in the middle of an interval) and start from ``n``:
+        the producer must never draw past the NEXT validation point of the loop that is starting now."""
+        while self._budget.acquire(blocking=False):
+            pass
+        self.grant(n)
+
     # ---- producer thread: DataLoader -> packed host arrays -------------------------------------------------
     def _put(self, q, item, stop):
         while not stop.is_set():  # a consumer that left early (break, exception) must not strand this thread
@@ -187,7 +194,13 @@ class DeviceFeeder:
         with torch.cuda.device(self.device):
             while True:
                 while not done and len(pending) < self.depth - 1:
-                    item = q.get()
+                    # With a draw budget the producer may be parked on it (grant() only comes after this consumer has
+                    # yielded): block for the batch that is needed NOW, take further ones only if they are already there
+                    # (depth >= 3 would otherwise wait for a batch beyond the budget: a deadlock at every validation point)
+                    try:
+                        item = q.get(block=not (self._limited and pending))
+                    except queue.Empty:
+                        break
                     if item is None:
                         done = True
                         break

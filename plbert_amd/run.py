@@ -163,12 +163,15 @@ def initialize_model(config, log_dir, resuming, device=None, max_batch=None):
 def _feeder(loader, trainer, word_separator, budget=None):
     """ONE DeviceFeeder per (trainer, loader): its pinned buffers, device slots and copy stream are created once (a fresh
     set per validation pass was measured as tens of slow steps after every pass)."""
+    import weakref
+
     from .pipeline import DeviceFeeder
-    cache = trainer.__dict__.setdefault("_feeders", {})
-    f = cache.get(id(loader))
+    # keyed by the loader OBJECT (weakly): id() can be handed to a new loader once the old one has been collected
+    cache = trainer.__dict__.setdefault("_feeders", weakref.WeakKeyDictionary())
+    f = cache.get(loader)
     if f is None:
-        f = cache[id(loader)] = DeviceFeeder(loader, device=trainer.engine.device, vocab_size=trainer.engine.cfg.vocab_size,
-                                             word_separator=word_separator, draw_budget=budget)
+        f = cache[loader] = DeviceFeeder(loader, device=trainer.engine.device, vocab_size=trainer.engine.cfg.vocab_size,
+                                         word_separator=word_separator, draw_budget=budget)
     return f
 
 
@@ -180,9 +183,14 @@ def _batches(loader, trainer, device_masking, word_separator, budget=None):
     if world == 1:
         yield from _feeder(loader, trainer, word_separator, budget)
         return
+    first = None
     for batch in loader:
-        lab, msk, lens, idx = shard_batch((np.asarray(batch[0]), np.asarray(batch[1]), batch[2], batch[3]), rank, world,
-                                          pad=True)  # a ragged last (validation) batch: accelerate's even_batches
+        cur = (np.asarray(batch[0]), np.asarray(batch[1]), batch[2], batch[3])
+        if first is None:
+            first = cur
+        # a short last (validation) batch: accelerate's even_batches=True completes it from the pass's first batch
+        lab, msk, lens, idx = shard_batch(cur, rank, world, pad=True, batch_size=getattr(loader, "batch_size", None),
+                                          first_batch=first)
         yield trainer.stage_batch(lab, msk, lens, idx)
 
 
@@ -191,6 +199,7 @@ def validate(trainer, val_loader, device_masking=False, word_separator=None):
     total, n = 0.0, 0
     for b in _batches(val_loader, trainer, device_masking, word_separator):
         total += float(trainer.engine.loss_fwd(b.masked, b.labels, b.lengths, b.offsets, b.flat, b.n_masked).item())
+        trainer.engine.raise_if_failed()
         n += 1
     return total / max(n, 1)
 
@@ -211,11 +220,14 @@ def train_loop(trainer, train_loader, val_loader, current_step, num_steps, save_
         if single:
             _feeder(train_loader, trainer, word_separator, 0).grant(save_interval - current_step % save_interval)
 
+    if single:  # permits an earlier loop with this trainer and loader left unused (it stopped at num_steps mid-interval)
+        _feeder(train_loader, trainer, word_separator, 0).reset_budget(0)
     grant()
     while epoch < max_epochs:
         epoch += 1
         for batch in _batches(train_loader, trainer, device_masking, word_separator, 0):
             loss = float(trainer.step(batch).item())            # the reference syncs here too (loss.item(), train.py:395)
+            trainer.engine.raise_if_failed()                     # the step has completed: its hand-off status is exact here
             current_step += 1
             window.append(loss)
             rec = {"phoneme_loss": loss, "epoch": epoch, "step": current_step}

@@ -66,6 +66,19 @@ def validate_batch(labels, masked, lengths, masked_indices, vocab_size):
                 raise ValueError(f"sample {b}: duplicate masked index")
 
 
+def _rewind_steps(owner):
+    """HandoffTimeout callback for an object that counts optimizer steps (``step_count``): the device skipped
+    ``err.skipped_updates`` of them. Holds the owner weakly (the engine must not keep its trainer alive)."""
+    import weakref
+    ref = weakref.ref(owner)
+
+    def cb(err):
+        o = ref()
+        if o is not None:
+            o.step_count = max(0, o.step_count - err.skipped_updates)
+    return cb
+
+
 class PLBertTrainer:
     """PhonemeOnlyModel + AdamW(lr) of train.py:266-272 on one GPU, optionally data parallel.
     ``num_tokens > 0`` builds MultiTaskModel's second head (model.py:11); batches staged with ``token_ids``
@@ -90,6 +103,9 @@ class PLBertTrainer:
         self.world = self.reducer.world
         sd = state_dict if state_dict is not None else reference_init_state_dict(cfg, num_phonemes, num_tokens, seed=seed)
         self.engine.load_state_dict(sd)
+        # a step whose fused LayerNorm hand-off timed out is skipped on the device (include/plbert.h: plb_status) and
+        # raises HandoffTimeout from the next engine call: the bias-correction count goes back by the skipped updates
+        self.engine._on_handoff_timeout.append(_rewind_steps(self))
         self.comm = "none"
         if self.reducer.active:
             if comm == "auto":
@@ -356,6 +372,7 @@ class AdamW:
         self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.step_count = 0
         self.grad_scale = 1.0
+        self.engine._on_handoff_timeout.append(_rewind_steps(self))
         by_id = {id(p): n for n, p in model.named_parameters()}
         self._names = [by_id[id(p)] for p in self.param_list]
 

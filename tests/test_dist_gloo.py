@@ -96,3 +96,30 @@ def test_shard_batch_edges():
     assert s1[0].tolist() == lab[2:4].tolist() and s1[2] == [3, 3] and s1[3] == [[], [2]]
     with pytest.raises(ValueError):
         shard_batch(b, 0, 4)
+
+
+def test_shard_batch_short_last_batch_follows_accelerate_even_batches():
+    """The reference prepares its loaders with Accelerator(split_batches=True) (train.py:218-221) and accelerate's default
+    even_batches=True: BatchSamplerShard completes a short last batch (drop_last=False: validation) to the FULL batch
+    size with the indices of the pass's first batch, and every rank takes batch_size // world of it. shard_batch with
+    the pass context must hand each rank exactly those samples (checked against accelerate's own sampler)."""
+    from accelerate.data_loader import BatchSamplerShard
+    from torch.utils.data import BatchSampler, SequentialSampler
+
+    from plbert_amd.dist import shard_batch
+
+    n, bs, world = 10, 4, 2
+    lab = np.arange(n * 3).reshape(n, 3)
+    lengths = [3] * n
+    idx = [[i % 3] for i in range(n)]
+    batches = [list(range(i, min(i + bs, n))) for i in range(0, n, bs)]          # what the un-sharded loader collates
+    collate = lambda ids: (lab[ids], lab[ids] + 1000, [lengths[i] for i in ids], [idx[i] for i in ids])
+    first = collate(batches[0])
+    for rank in range(world):
+        acc = list(BatchSamplerShard(BatchSampler(SequentialSampler(range(n)), bs, drop_last=False), num_processes=world,
+                                     process_index=rank, split_batches=True, even_batches=True))
+        assert len(acc) == len(batches)
+        for ids, want in zip(batches, acc):
+            got = shard_batch(collate(ids), rank, world, pad=True, batch_size=bs, first_batch=first)
+            assert got[0][:, 0].tolist() == [3 * i for i in want], (rank, ids, want)
+            assert got[3] == [idx[i] for i in want]

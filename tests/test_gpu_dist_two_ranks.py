@@ -48,6 +48,7 @@ def _worker(rank, world, port, out):
     lab, msk, lens, idx = shard_batch(batch, rank, world)
     loss = tr.step(tr.stage_batch(lab, msk, lens, idx))
     torch.cuda.synchronize()
+    assert tr.engine.status()["ln_exchange_timeouts"] == 0
     out[rank] = (float(loss.item()), {k: v.cpu().numpy() for k, v in tr.engine.state_dict().items()})
     dist.barrier()
     dist.destroy_process_group()

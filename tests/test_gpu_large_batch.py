@@ -16,8 +16,12 @@ from plbert_amd.train import PLBertTrainer
 pytestmark = pytest.mark.gpu
 
 
-def test_96x512_step():
-    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=256, num_attention_heads=4, intermediate_size=512,
+@pytest.mark.parametrize("hidden,heads,inter", [(256, 4, 512), (768, 12, 2048)])
+def test_96x512_step(hidden, heads, inter):
+    """hidden 768: the fused LayerNorm launches have 384 row blocks x 2 column tiles = 768 workgroups on 256 CUs — three
+    rounds, the one shape in the suite where the two members of a hand-off are not trivially co-resident from the start
+    (forward progress rests on adjacent dispatch slots; the bounded wait's error word must stay 0)."""
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=hidden, num_attention_heads=heads, intermediate_size=inter,
                                   max_position_embeddings=512, num_hidden_layers=2)
     B, S = 96, 512
     labels, masked, lens, idx = plbert_amd.synthetic_batch(B, S, seed=31)
@@ -54,6 +58,7 @@ def test_96x512_step():
     for _ in range(3):
         l2 = float(tr.step(full).item())
     assert l2 < l1
+    assert eng.status()["ln_exchange_timeouts"] == 0
 
 
 def test_embed_scatter_matches_index_add_beyond_one_chunk():
