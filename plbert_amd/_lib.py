@@ -103,6 +103,8 @@ class PlbAttn(C.Structure):
         ("ctx", C.c_void_p), ("ldctx", C.c_int), ("lse", C.c_void_p),
         ("dctx", C.c_void_p), ("lddctx", C.c_int), ("delta", C.c_void_p), ("dqkv", C.c_void_p), ("lddqkv", C.c_int),
         ("colpart", C.c_void_p), ("colpart_accumulate", C.c_int),
+        ("ctx8", C.c_void_p), ("ldctx8", C.c_int), ("ctx_scale", C.c_void_p), ("ctx_amax", C.c_void_p),
+        ("dqkv8", C.c_void_p), ("lddqkv8", C.c_int), ("dqkv_scale", C.c_void_p), ("dqkv_amax", C.c_void_p),
     ]
 
 
@@ -228,6 +230,10 @@ def lib():
     L.plb_set_gemm_nt_prefetch.argtypes = [C.c_int]
     L.plb_launch_gemm_nt_fp8.restype = C.c_int
     L.plb_launch_gemm_nt_fp8.argtypes = [C.POINTER(PlbGemmNT), C.c_int, C.c_int, vp]
+    L.plb_launch_gemm_nt_fp8_ln.restype = C.c_int
+    L.plb_launch_gemm_nt_fp8_ln.argtypes = [C.POINTER(PlbGemmNT), C.c_int, C.c_int, vp]
+    L.plb_launch_gemm_nt_fp8_gelud.restype = C.c_int
+    L.plb_launch_gemm_nt_fp8_gelud.argtypes = [C.POINTER(PlbGemmNT), C.c_int, C.c_int, vp]
     L.plb_launch_gemm_tn.restype = C.c_int
     L.plb_launch_gemm_tn.argtypes = [C.POINTER(PlbGemmTN), vp]
     L.plb_launch_gemm_tn_big.restype = C.c_int

@@ -158,8 +158,16 @@ __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
   // all waves are past the last barrier: reuse the staging LDS as per-wave transpose patches
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
   int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
+  // fp8 mode: the e4m3 image of the context rows for the fp8 dense projection and its weight gradient
+  const Out8 o8 = {p.ctx8 ? p.ctx8 + (tok0 + q0) * p.ldctx8 + hd * 64 : nullptr, p.ldctx8, p.ctx8 ? p.ctx_scale[0] : 1.0f, false};
+  float amax8 = 0.f;
   if (rows_valid > 0)
-    store_transposed<(ATTN_OUT_NT & 1) != 0>(o0, o1, inv, patch, p.ctx + (tok0 + q0) * p.ldctx + hd * 64, p.ldctx, rows_valid, lane);
+    store_transposed<(ATTN_OUT_NT & 1) != 0>(o0, o1, inv, patch, p.ctx + (tok0 + q0) * p.ldctx + hd * 64, p.ldctx, rows_valid, lane,
+                                             nullptr, false, &o8, &amax8);
+  if (p.ctx8 && p.ctx_amax) {
+    amax8 = wave_max(amax8);
+    if (lane == 0) atomic_max_abs(p.ctx_amax, amax8, blockIdx.x * 4 + wave);
+  }
 }
 
 // ------------------------------------------------------------------------------------- backward dQ
@@ -289,10 +297,17 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
   int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
   // bias-gradient partial row of this wave: [(b * QT + q tile) * 4 + wave][3H], columns hd*64.. of the Q block
   float* cp = p.colpart ? p.colpart + ((size_t)(b * QT + bx) * 4 + wave) * (3 * H) + hd * 64 : nullptr;
+  // fp8 mode: the e5m2 image of the gradient rows for the fp8 dX GEMM and the QKV weight gradient (dqkv itself may be off)
+  const Out8 o8 = {p.dqkv8 ? p.dqkv8 + (tok0 + q0) * p.lddqkv8 + hd * 64 : nullptr, p.lddqkv8, p.dqkv8 ? p.dqkv_scale[0] : 1.0f, true};
+  float amax8 = 0.f;
   if (rows_valid > 0)
-    store_transposed<(ATTN_OUT_NT & 2) != 0>(dq0, dq1, p.scale, patch, p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64, p.lddqkv, rows_valid, lane, cp,
-                     p.colpart_accumulate != 0);
+    store_transposed<(ATTN_OUT_NT & 2) != 0>(dq0, dq1, p.scale, patch, p.dqkv ? p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64 : nullptr, p.lddqkv,
+                     rows_valid, lane, cp, p.colpart_accumulate != 0, &o8, &amax8);
   else if (cp && !p.colpart_accumulate) cp[lane] = 0.f;
+  if (p.dqkv8 && p.dqkv_amax) {
+    amax8 = wave_max(amax8);
+    if (lane == 0) atomic_max_abs(p.dqkv_amax, amax8, blockIdx.x * 4 + wave);
+  }
 }
 
 // ---------------------------------------------------------------------------------- backward dK,dV
@@ -471,15 +486,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   // the thread id it comes from — were the kernel's two spilled registers (256 VGPRs in the loop)
   int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   asm volatile("" : "+v"(lane_e));
+  float amax8 = 0.f;
   if (rows_valid > 0) {
-    bf16_t* out = p.dqkv + (tok0 + key0) * p.lddqkv + hd * 64;
+    bf16_t* out = p.dqkv ? p.dqkv + (tok0 + key0) * p.lddqkv + hd * 64 : nullptr;
+    uint8_t* out8 = p.dqkv8 ? p.dqkv8 + (tok0 + key0) * p.lddqkv8 + hd * 64 : nullptr;
+    const float qs8 = p.dqkv8 ? p.dqkv_scale[0] : 1.0f;
+    const Out8 ok8 = {out8 ? out8 + H : nullptr, p.lddqkv8, qs8, true}, ov8 = {out8 ? out8 + 2 * H : nullptr, p.lddqkv8, qs8, true};
     const bool accq = p.colpart_accumulate != 0;
-    store_transposed<(ATTN_OUT_NT & 4) != 0>(dk0, dk1, p.scale, patch, out + H, p.lddqkv, rows_valid, lane_e, cp ? cp + H : nullptr, accq);
+    store_transposed<(ATTN_OUT_NT & 4) != 0>(dk0, dk1, p.scale, patch, out ? out + H : nullptr, p.lddqkv, rows_valid, lane_e,
+                                             cp ? cp + H : nullptr, accq, &ok8, &amax8);
     __builtin_amdgcn_wave_barrier();
-    store_transposed<(ATTN_OUT_NT & 4) != 0>(dv0, dv1, 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane_e, cp ? cp + 2 * H : nullptr, accq);
+    store_transposed<(ATTN_OUT_NT & 4) != 0>(dv0, dv1, 1.0f, patch, out ? out + 2 * H : nullptr, p.lddqkv, rows_valid, lane_e,
+                                             cp ? cp + 2 * H : nullptr, accq, &ov8, &amax8);
   } else if (cp && !p.colpart_accumulate) {
     cp[H + lane_e] = 0.f;
     cp[2 * H + lane_e] = 0.f;
+  }
+  if (p.dqkv8 && p.dqkv_amax) {
+    amax8 = wave_max(amax8);
+    if (lane_e == 0) atomic_max_abs(p.dqkv_amax, amax8, blockIdx.x * 4 + wave);
   }
 }
 
@@ -492,7 +517,7 @@ static int check_attn(const PlbAttn* p) {
 }
 
 extern "C" int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream) {
-  if (check_attn(p)) return 1;
+  if (check_attn(p) || (p->ctx8 && (!p->ctx_scale || p->ldctx8 % 8))) return 1;
   dim3 grid(((p->S + 127) / 128) * p->NH * p->B), block(256);
   const double unit = (double)p->B * p->NH * (double)p->S * p->S * 64.0;
   const double io = 2.0 * p->B * p->S * (double)p->H;
@@ -510,12 +535,12 @@ static int g_bwd_fused = -1;
 extern "C" void plb_set_attn_bwd_fused(int on) { g_bwd_fused = on ? 1 : 0; }
 
 extern "C" int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream) {
-  if (check_attn(p) || p->lddctx % 8 || p->lddqkv % 8) return 1;
+  if (check_attn(p) || p->lddctx % 8 || p->lddqkv % 8 || (!p->dqkv && !p->dqkv8) || (p->dqkv8 && (!p->dqkv_scale || p->lddqkv8 % 8))) return 1;
   if (g_bwd_fused < 0) {
     const char* e = getenv("PLBERT_ATTN_BWD");
     g_bwd_fused = (e && !strcmp(e, "fused")) ? 1 : 0;
   }
-  if (g_bwd_fused && p->S <= 512) return plb_launch_attn_bwd_fused(p, stream);
+  if (g_bwd_fused && p->S <= 512 && p->dqkv && !p->dqkv8) return plb_launch_attn_bwd_fused(p, stream);  // (no fp8 image in the fused form)
   dim3 grid(((p->S + 127) / 128) * p->NH * p->B), block(256);
   // algorithmic work of the backward = 4 products (dP, dQ, dV, dK); the S recomputation in each
   // kernel and the second dP are not credited

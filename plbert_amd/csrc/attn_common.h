@@ -110,9 +110,13 @@ DEVI f32x16 zero16() {
 #ifndef ATTN_OUT_NT
 #define ATTN_OUT_NT 0
 #endif
+// Optional fp8 copy of the rows a wave stores (fp8 mode): the values AS ROUNDED TO bf16 times qs, saturated, e4m3 or e5m2;
+// amax = running max |value| of the lane (the caller reduces it and reports it to the site). g8 == nullptr: off.
+struct Out8 { uint8_t* g8; int ld8; float qs; bool bf8; };
 template <bool NT = false>
 DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_t* patch, bf16_t* gout, int ldo,
-                           int rows_valid, int lane, float* colsum = nullptr, bool accumulate = false) {
+                           int rows_valid, int lane, float* colsum = nullptr, bool accumulate = false,
+                           const Out8* o8 = nullptr, float* amax = nullptr) {
   constexpr int PS = 72;  // elements per patch row (144 B)
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -134,8 +138,21 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
     uint4 v = *(const uint4*)&patch[row * PS + c * 8];
     if (row < rows_valid && (!(ATTN_DBG & 128) || v.x == 0x12345678u)) {
       typedef unsigned int u32x4nt_ __attribute__((ext_vector_type(4)));
-      if constexpr (NT) __builtin_nontemporal_store(u32x4nt_{v.x, v.y, v.z, v.w}, (u32x4nt_*)(gout + (size_t)row * ldo + c * 8));
-      else *(uint4*)(gout + (size_t)row * ldo + c * 8) = v;
+      if (gout) {
+        if constexpr (NT) __builtin_nontemporal_store(u32x4nt_{v.x, v.y, v.z, v.w}, (u32x4nt_*)(gout + (size_t)row * ldo + c * 8));
+        else *(uint4*)(gout + (size_t)row * ldo + c * 8) = v;
+      }
+      if (o8 && o8->g8) {
+        const float f0 = bf_lo(v.x), f1 = bf_hi(v.x), f2 = bf_lo(v.y), f3 = bf_hi(v.y);
+        const float f4 = bf_lo(v.z), f5 = bf_hi(v.z), f6 = bf_lo(v.w), f7 = bf_hi(v.w);
+        const float q = o8->qs;
+        uint2 w;
+        w.x = pack_fp8x4(f0 * q, f1 * q, f2 * q, f3 * q, o8->bf8);
+        w.y = pack_fp8x4(f4 * q, f5 * q, f6 * q, f7 * q, o8->bf8);
+        *(uint2*)(o8->g8 + (size_t)row * o8->ld8 + c * 8) = w;
+        *amax = fmaxf(*amax, fmaxf(fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(f3))),
+                                   fmaxf(fmaxf(fabsf(f4), fabsf(f5)), fmaxf(fabsf(f6), fabsf(f7)))));
+      }
     }
   }
   if (colsum && !(ATTN_DBG & 64)) {

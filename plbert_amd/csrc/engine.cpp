@@ -50,7 +50,8 @@ const char* const kClassNames[PLB_K_NCLASS] = {
     "gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32", "gemm_tn", "attn_fwd", "attn_bwd_dq", "attn_bwd_dkv",
     "ln_fwd", "ln_bwd", "embed_fwd", "embed_bwd", "colsum", "reduce_slabs", "gather_scatter_rows", "cross_entropy",
     "adamw", "cast_transpose", "token_ce", "gemm_nt_ce", "gemm_nt_small", "fp8_quantize", "attn_bwd", "gemm_nt_fp8",
-    "gemm_nt_gelu_fp8", "gemm_nt_gelubwd_fp8", "gemm_nt_lnfwd", "gemm_nt_lnbwd"};
+    "gemm_nt_gelu_fp8", "gemm_nt_gelubwd_fp8", "gemm_nt_lnfwd", "gemm_nt_lnbwd", "gemm_nt_lnfwd_fp8", "gemm_nt_lnbwd_fp8",
+    "gemm_tn_fp8"};
 hipEvent_t prof_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e = nullptr;
@@ -189,8 +190,12 @@ struct PlbEngine {
   // fp8 mode (plb_set_fp8): transient 1-byte images of the fp8 GEMMs' activation / gradient operands, fp8 weight copies
   // and the per-(site, layer) delayed-scaling state [amax | scale | deq] (+ one entry per weight copy)
   bool fp8_on = false, fp8_ready = false, fp8_bwd_ready = false, fp8_wstale = true;
-  int64_t o_x8 = 0, o_a8 = 0, o_g8 = 0, o_dp8 = 0, o_du8 = 0;
-  int64_t o_wq8 = 0, o_w18 = 0, o_w28 = 0, o_w2T8 = 0, o_w1T8 = 0;
+  bool fp8_tn = false;          // the weight-gradient GEMMs run on the 1-byte images too (PLBERT_FP8_TN=0: bf16 operands)
+  // per-layer 1-byte images [Ls][Tp][width] of every GEMM operand that is an activation (e4m3: layer input x, context,
+  // attention-block output a, gelu output g) or a gradient (e5m2: dpre2, dU, dpre1, dQKV): read by the next NT GEMM and,
+  // all layers at once, by the token-major weight-gradient GEMMs
+  int64_t o_x8 = 0, o_a8 = 0, o_g8 = 0, o_c8 = 0, o_dp8 = 0, o_du8 = 0, o_dp18 = 0, o_dq8 = 0;
+  int64_t o_wq8 = 0, o_wd8 = 0, o_w18 = 0, o_w28 = 0, o_w2T8 = 0, o_w1T8 = 0, o_wqT8 = 0, o_wdT8 = 0;
   int64_t o_f8amax = 0, o_f8scale = 0, o_f8deq = 0;
   int f8n = 0;
   bool infer = false;           // inference-only workspace: one layer of activations, no gradient stash
@@ -414,17 +419,20 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
       e->o_tgrad = cv.take(NTp * H * 4);
     }
   }
-  // fp8 mode: operand images of ONE layer (the bf16 stash stays the backward's source) and the weight copies
-  e->o_x8 = cv.take(Tp * H); e->o_a8 = cv.take(Tp * H); e->o_g8 = cv.take(Tp * I);
+  // fp8 mode: 1-byte operand images of every layer kept (training: all of them, for the weight gradients) and the weight copies
+  e->o_x8 = cv.take(Ls * Tp * H); e->o_a8 = cv.take(Ls * Tp * H); e->o_g8 = cv.take(Ls * Tp * I); e->o_c8 = cv.take(Ls * Tp * H);
   e->o_wq8 = cv.take(rup(3 * H, 128) * H + 256 * H);
+  e->o_wd8 = cv.take(rup(H, 128) * H + 256 * H);
   e->o_w18 = cv.take(rup(I, 128) * H + 256 * H);
   e->o_w28 = cv.take(rup(H, 128) * I + 256 * I);
   if (tr) {
-    e->o_dp8 = cv.take(Tp * H); e->o_du8 = cv.take(Tp * I);
+    e->o_dp8 = cv.take(L * Tp * H); e->o_du8 = cv.take(L * Tp * I); e->o_dp18 = cv.take(L * Tp * H); e->o_dq8 = cv.take(L * Tp * 3 * H);
     e->o_w2T8 = cv.take(rup(I, 128) * H + 256 * H);
     e->o_w1T8 = cv.take(rup(H, 128) * I + 256 * I);
+    e->o_wqT8 = cv.take(rup(H, 128) * 3 * H + 256 * 3 * H);
+    e->o_wdT8 = cv.take(rup(H, 128) * H + 256 * H);
   }
-  e->f8n = 5 * (int)L + 5;
+  e->f8n = 8 * (int)L + 8;
   e->o_f8amax = cv.take((int64_t)e->f8n * 64 * 16 * 4); e->o_f8scale = cv.take(e->f8n * 4); e->o_f8deq = cv.take(e->f8n * 4);
   e->ws_bytes = cv.off;
   *out = e;
@@ -502,9 +510,9 @@ extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_av
 // ---- fp8 mode ---------------------------------------------------------------------------------------------------------
 // Sites: activations X (layer input), A (attention block output), G (gelu output) in e4m3; gradients DP (dpre2) and DU
 // in e5m2 (their range within a tensor is what e5m2's five exponent bits are for); weights W* in e4m3.
-enum { F8_X = 0, F8_A, F8_G, F8_DP, F8_DU, F8_NSITE };
+enum { F8_X = 0, F8_A, F8_G, F8_C, F8_DP, F8_DU, F8_DP1, F8_DQ, F8_NSITE };   // 4 activation sites, then 4 gradient sites
 enum { F8_AMAX_WORDS = 64 * 16 };  // floats per site in the amax array (common.h: F8_SLOTS x F8_STRIDE)
-enum { F8W_QKV = 0, F8W_1, F8W_2, F8W_2T, F8W_1T };
+enum { F8W_QKV = 0, F8W_D, F8W_1, F8W_2, F8W_2T, F8W_1T, F8W_QKVT, F8W_DT, F8W_N };
 static int f8_site(const PlbEngine* e, int site, int l) { return site * e->L + l; }
 static int f8_w(const PlbEngine* e, int w) { return F8_NSITE * e->L + w; }
 static float* f8_amax(const PlbEngine* e, int i) { return e->at<float>(e->o_f8amax) + (int64_t)i * F8_AMAX_WORDS; }
@@ -520,18 +528,21 @@ static bool fp8_shapes_ok(const PlbEngine* e, int64_t Tp) {
 // per-tensor e4m3 copies of the fp8 GEMMs' weights (exact amax: the weights are known)
 static int fp8_quantize_weights(PlbEngine* e, hipStream_t s) {
   const int H = e->H, I = e->I;
-  struct W { int w; const void* src; int bf16; int rows, cols; int64_t dst; } ws[5] = {
+  struct W { int w; const void* src; int bf16; int rows, cols; int64_t dst; } ws[F8W_N] = {
       {F8W_QKV, e->par(PLB_Q_W), 0, 3 * H, H, e->o_wq8},
+      {F8W_D, e->par(PLB_DENSE_W), 0, H, H, e->o_wd8},
       {F8W_1, e->par(PLB_FFN_W), 0, I, H, e->o_w18},
       {F8W_2, e->par(PLB_FFNO_W), 0, H, I, e->o_w28},
       {F8W_2T, e->infer ? nullptr : e->at<bf16_t>(e->o_w2T), 1, I, H, e->o_w2T8},
-      {F8W_1T, e->infer ? nullptr : e->at<bf16_t>(e->o_w1T), 1, H, I, e->o_w1T8}};
-  HIPTRY(hipMemsetAsync(f8_amax(e, f8_w(e, 0)), 0, 5 * F8_AMAX_WORDS * sizeof(float), s));
+      {F8W_1T, e->infer ? nullptr : e->at<bf16_t>(e->o_w1T), 1, H, I, e->o_w1T8},
+      {F8W_QKVT, e->infer ? nullptr : e->at<bf16_t>(e->o_wqkvT), 1, H, 3 * H, e->o_wqT8},
+      {F8W_DT, e->infer ? nullptr : e->at<bf16_t>(e->o_wdT), 1, H, H, e->o_wdT8}};
+  HIPTRY(hipMemsetAsync(f8_amax(e, f8_w(e, 0)), 0, F8W_N * F8_AMAX_WORDS * sizeof(float), s));
   for (auto& w : ws) {
     if (!w.src) continue;
     TRY(plb_launch_amax(w.src, w.bf16, (size_t)w.rows, w.cols, w.cols, f8_amax(e, f8_w(e, w.w)), s));
   }
-  TRY(plb_launch_fp8_scales(f8_amax(e, f8_w(e, 0)), f8_scale(e, f8_w(e, 0)), f8_deq(e, f8_w(e, 0)), 5, 448.f, s));
+  TRY(plb_launch_fp8_scales(f8_amax(e, f8_w(e, 0)), f8_scale(e, f8_w(e, 0)), f8_deq(e, f8_w(e, 0)), F8W_N, 448.f, s));
   for (auto& w : ws) {
     if (!w.src) continue;
     TRY(plb_launch_quantize(w.src, w.bf16, (size_t)w.rows, w.cols, w.cols, f8_scale(e, f8_w(e, w.w)), e->at<uint8_t>(w.dst),
@@ -543,8 +554,8 @@ static int fp8_quantize_weights(PlbEngine* e, hipStream_t s) {
 // end of a call in fp8 mode: this call's maxima become the next call's scales (delayed scaling, history 1)
 static int fp8_update_scales(PlbEngine* e, hipStream_t s) {
   const int L = e->L;
-  TRY(plb_launch_fp8_scales(f8_amax(e, 0), f8_scale(e, 0), f8_deq(e, 0), 3 * L, 448.f, s));          // X, A, G: e4m3
-  TRY(plb_launch_fp8_scales(f8_amax(e, 3 * L), f8_scale(e, 3 * L), f8_deq(e, 3 * L), 2 * L, 57344.f, s));  // DP, DU: e5m2
+  TRY(plb_launch_fp8_scales(f8_amax(e, 0), f8_scale(e, 0), f8_deq(e, 0), 4 * L, 448.f, s));                // X, A, G, C: e4m3
+  TRY(plb_launch_fp8_scales(f8_amax(e, 4 * L), f8_scale(e, 4 * L), f8_deq(e, 4 * L), 4 * L, 57344.f, s));  // DP, DU, DP1, DQ: e5m2
   return 0;
 }
 
@@ -613,25 +624,45 @@ static int check_shape(const PlbEngine* e, int B, int S, const char* who) {
 // One NT GEMM of the fp8 set: the fp8 launch when the call runs in fp8 mode (A8 / B8 images, their dequantisation
 // factors), else the bf16 launch on A / B. g carries everything else (shapes, bias, residual, outputs).
 struct F8Op { const uint8_t* A8; const uint8_t* B8; const float* deq_a; const float* deq_b; int a_bf8; };
-static int gemm_nt_any(PlbGemmNT* g, int act, const F8Op* f8, hipStream_t s) {
-  if (!f8) return plb_launch_gemm_nt(g, act, 0, s);
+static PlbGemmNT f8_operands(const PlbGemmNT* g, const F8Op* f8) {
   PlbGemmNT q = *g;
   q.A = reinterpret_cast<const bf16_t*>(f8->A8); q.B = reinterpret_cast<const bf16_t*>(f8->B8);
   q.deq_a = f8->deq_a; q.deq_b = f8->deq_b;
+  return q;
+}
+static int gemm_nt_any(PlbGemmNT* g, int act, const F8Op* f8, hipStream_t s) {
+  if (!f8) return plb_launch_gemm_nt(g, act, 0, s);
+  PlbGemmNT q = f8_operands(g, f8);
   return plb_launch_gemm_nt_fp8(&q, act, f8->a_bf8, s);
 }
+// the LayerNorm forms (5 / 6) and the gelu-derivative-stash forms, bf16 or fp8 operands
+static int gemm_nt_ln_any(PlbGemmNT* g, int mode, const F8Op* f8, hipStream_t s) {
+  if (!f8) return plb_launch_gemm_nt_ln(g, mode, s);
+  PlbGemmNT q = f8_operands(g, f8);
+  return plb_launch_gemm_nt_fp8_ln(&q, mode, f8->a_bf8, s);
+}
+static int gemm_nt_gelud_any(PlbGemmNT* g, int backward, const F8Op* f8, hipStream_t s) {
+  if (!f8) return plb_launch_gemm_nt_gelud(g, backward, s);
+  PlbGemmNT q = f8_operands(g, f8);
+  return plb_launch_gemm_nt_fp8_gelud(&q, backward, f8->a_bf8, s);
+}
+// the 1-byte image + running maximum a launch writes beside its output (site i: scale in, maxima out)
+static void f8_out(const PlbEngine* e, PlbGemmNT* g, uint8_t* img, int ld, int site, int bf8) {
+  g->C8 = img; g->ldc8 = ld; g->q_scale = f8_scale(e, site); g->q_amax = f8_amax(e, site); g->c8_bf8 = bf8;
+}
 
-// LayerNorm in the epilogue of the GEMM that produces its input (gemm_ln.hip): the shapes it exists for. Not in calls
-// that run the fp8 GEMMs (the LayerNorm kernels also write the fp8 images there); an fp8 CALIBRATION call computes in
-// bf16 and fuses like any bf16 call (it must equal the bf16 path bit for bit: tests/test_gpu_fp8.py).
-static bool ln_fusable(const PlbEngine* e, int64_t Tp, int bit, bool f8_call) {
+// LayerNorm in the epilogue of the GEMM that produces its input (gemm_ln.hip, gemm_fp8_ln.hip): the shapes it exists for,
+// in bf16 and in fp8 calls alike (the fp8 forms write the 1-byte images the standalone LayerNorm kernels used to write);
+// an fp8 CALIBRATION call computes in bf16 (it must equal the bf16 path bit for bit: tests/test_gpu_fp8.py).
+static bool ln_fusable(const PlbEngine* e, int64_t Tp, int bit) {
   const int H = e->H;
-  return (e->ln_fuse & bit) && !f8_call && Tp % 1024 == 0 && (H % 384 == 0 ? H / 384 : H % 256 == 0 ? H / 256 : 99) <= 4;
+  return (e->ln_fuse & bit) && Tp % 1024 == 0 && (H % 384 == 0 ? H / 384 : H % 256 == 0 ? H / 256 : 99) <= 4;
 }
 // Does the forward of this call stash gelu_new'(u) instead of u (plb_launch_gemm_nt_gelud)? Recorded in the engine: the
-// backward of the same call must read the stash the way the forward wrote it.
+// backward of the same call must read the stash the way the forward wrote it — the stash is in the LANE layout of the
+// tile that wrote it (256x256 in bf16 calls, 128x256 in fp8 calls), so forward and backward of a call run in one mode.
 static bool gelu_dstash(PlbEngine* e, int64_t Tp, bool f8_call) {
-  e->u_is_derivative = e->gelu_dstash_on && !f8_call && Tp % 256 == 0 && e->I % 256 == 0;  // (an fp8 calibration call computes in bf16)
+  e->u_is_derivative = e->gelu_dstash_on && (f8_call ? Tp % 128 == 0 : Tp % 256 == 0) && e->I % 256 == 0;
   return e->u_is_derivative;
 }
 static void ln_fields(const PlbEngine* e, PlbGemmNT* g, const float* gamma, const float* beta, float* mean, float* rstd) {
@@ -641,20 +672,23 @@ static void ln_fields(const PlbEngine* e, PlbGemmNT* g, const float* gamma, cons
 
 // Embeddings + L applications of the shared layer. stash: keep every layer's activations (training)
 // or reuse the layer-0 slots (inference). Returns the final hidden buffer in *xout.
-// fp8 mode: the QKV and the two FFN GEMMs run on e4m3 images — the LayerNorm kernels and the gelu epilogue write them
-// beside their bf16 outputs, each with the scale its site learnt in the previous call; a calibration call (the first
-// after plb_set_fp8) runs in bf16 and only records the maxima.
+// fp8 mode: EVERY large GEMM of the layer runs on 1-byte images — QKV, dense (+ LayerNorm 1), FFN up (+ gelu), FFN output
+// (+ LayerNorm 2) on e4m3 images of x, the attention context, a and gelu(u). Each image is written, with the scale its
+// site learnt in the previous call, by the launch that produces the tensor (the fused LayerNorm / gelu epilogues, the
+// attention kernel; the standalone LayerNorm kernels on shapes without a fused form), one image per layer in a training
+// call: the weight-gradient GEMMs read them all at the end of the backward. A calibration call (the first after
+// plb_set_fp8, and a training call whose gradient sites have not been seen yet) runs in bf16 and only records the maxima.
+static bool f8_call(const PlbEngine* e, int64_t Tp, bool train) {
+  return e->fp8_on && e->fp8_ready && (!train || e->fp8_bwd_ready) && fp8_shapes_ok(e, Tp);
+}
 static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths, int B, int S, bool stash, bf16_t** xout,
                        hipStream_t s) {
   const int E = e->E, H = e->H, I = e->I, L = e->L;
   const int T = B * S;
   const int64_t Tp = rup(T, 128);
-  const bool f8 = e->fp8_on && e->fp8_ready && fp8_shapes_ok(e, Tp);
-  const bool calib = e->fp8_on && !e->fp8_ready;
+  const bool f8 = f8_call(e, Tp, stash);
+  const bool calib = e->fp8_on && !f8;
   if (e->fp8_on && e->fp8_wstale) TRY(fp8_quantize_weights(e, s));
-  uint8_t* x8 = e->at<uint8_t>(e->o_x8);
-  uint8_t* a8 = e->at<uint8_t>(e->o_a8);
-  uint8_t* g8 = e->at<uint8_t>(e->o_g8);
   PlbEmbed em;
   memset(&em, 0, sizeof(em));
   em.ids = ids; em.T = T; em.S = S; em.E = E; em.V = e->V;
@@ -670,9 +704,11 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
   g.bias = e->par(PLB_MAP_B); g.C = xall; g.ldc = H;
   TRY(plb_launch_gemm_nt(&g, 0, 0, s));
   if (f8) {  // layer 0 reads the map-in output, which no LayerNorm produced: one quantisation pass
-    TRY(plb_launch_quantize(xall, 1, (size_t)T, H, H, f8_scale(e, f8_site(e, F8_X, 0)), x8, H, 0, s));
+    TRY(plb_launch_quantize(xall, 1, (size_t)T, H, H, f8_scale(e, f8_site(e, F8_X, 0)), e->at<uint8_t>(e->o_x8), H, 0, s));
     TRY(plb_launch_amax(xall, 1, (size_t)T, H, H, f8_amax(e, f8_site(e, F8_X, 0)), s));
   }
+  const bool fuse_f = ln_fusable(e, Tp, 1);
+  const bool dstash = gelu_dstash(e, Tp, f8);
 
   for (int l = 0; l < L; ++l) {
     const int64_t sl = stash ? l : 0;
@@ -685,7 +721,13 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     bf16_t* u = e->at<bf16_t>(e->o_u) + sl * Tp * I;
     bf16_t* gl = e->at<bf16_t>(e->o_g) + sl * Tp * I;
     bf16_t* pre2 = e->at<bf16_t>(e->o_pre2) + sl * Tp * H;
-    const int sX = f8_site(e, F8_X, l), sA = f8_site(e, F8_A, l), sG = f8_site(e, F8_G, l);
+    // this layer's 1-byte images; the next layer's input image (inference: the one slot, consumed before it is rewritten)
+    uint8_t* x8 = e->at<uint8_t>(e->o_x8) + sl * Tp * H;
+    uint8_t* x8n = e->at<uint8_t>(e->o_x8) + (stash ? (int64_t)(l + 1) : 0) * Tp * H;
+    uint8_t* c8 = e->at<uint8_t>(e->o_c8) + sl * Tp * H;
+    uint8_t* a8 = e->at<uint8_t>(e->o_a8) + sl * Tp * H;
+    uint8_t* g8 = e->at<uint8_t>(e->o_g8) + sl * Tp * I;
+    const int sX = f8_site(e, F8_X, l), sA = f8_site(e, F8_A, l), sG = f8_site(e, F8_G, l), sC = f8_site(e, F8_C, l);
     if (calib) TRY(plb_launch_amax(x, 1, (size_t)T, H, H, f8_amax(e, sX), s));
     // fused QKV projection
     memset(&g, 0, sizeof(g));
@@ -698,19 +740,22 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     at.qkv = qkv; at.ldqkv = 3 * H; at.lengths = lengths; at.B = B; at.S = S; at.NH = e->NH; at.H = H;
     at.scale = 0.125f; at.ctx = ctx; at.ldctx = H;
     at.lse = e->at<float>(e->o_lse) + sl * (int64_t)B * e->NH * S;
+    if (f8) { at.ctx8 = c8; at.ldctx8 = H; at.ctx_scale = f8_scale(e, sC); at.ctx_amax = f8_amax(e, sC); }
     TRY(plb_launch_attn_fwd(&at, s));
+    if (calib) TRY(plb_launch_amax(ctx, 1, (size_t)T, H, H, f8_amax(e, sC), s));
     // dense + residual, LayerNorm
     memset(&g, 0, sizeof(g));
     g.A = ctx; g.lda = H; g.B = e->wbf(PLB_DENSE_W); g.ldb = H; g.M = (int)Tp; g.N = H; g.K = H; g.Mstore = (int)Tp;
     g.bias = e->par(PLB_DENSE_B); g.res = x; g.ldr = H; g.C = pre1; g.ldc = H;
-    const bool fuse_f = ln_fusable(e, Tp, 1, f8);
+    F8Op od = {c8, e->at<uint8_t>(e->o_wd8), f8_deq(e, sC), f8_deq(e, f8_w(e, F8W_D)), 0};
     PlbLayerNorm ln;
     if (fuse_f) {  // dense + residual + LayerNorm in one launch
       g.C2 = a; g.ldc2 = H;
       ln_fields(e, &g, e->par(PLB_LN1_W), e->par(PLB_LN1_B), e->at<float>(e->o_mean1) + sl * Tp, e->at<float>(e->o_rstd1) + sl * Tp);
-      TRY(plb_launch_gemm_nt_ln(&g, 5, s));
+      if (f8) f8_out(e, &g, a8, H, sA, 0);
+      TRY(gemm_nt_ln_any(&g, 5, f8 ? &od : nullptr, s));
     } else {
-      TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+      TRY(gemm_nt_any(&g, 0, f8 ? &od : nullptr, s));
       memset(&ln, 0, sizeof(ln));
       ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.beta = e->par(PLB_LN1_B); ln.eps = e->c.layer_norm_eps;
       ln.y = a; ln.ldy = H; ln.T = T; ln.H = H;
@@ -723,30 +768,38 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     memset(&g, 0, sizeof(g));
     g.A = a; g.lda = H; g.B = e->wbf(PLB_FFN_W); g.ldb = H; g.M = (int)Tp; g.N = I; g.K = H; g.Mstore = (int)Tp;
     g.bias = e->par(PLB_FFN_B); g.C = u; g.ldc = I; g.C2 = gl; g.ldc2 = I;
-    if (f8) { g.C8 = g8; g.ldc8 = I; g.q_scale = f8_scale(e, sG); g.q_amax = f8_amax(e, sG); g.c8_bf8 = 0; }
+    if (f8) f8_out(e, &g, g8, I, sG, 0);
     F8Op o1 = {a8, e->at<uint8_t>(e->o_w18), f8_deq(e, sA), f8_deq(e, f8_w(e, F8W_1)), 0};
-    // bf16 calls on 256-multiples stash gelu_new'(u) in the "u" slot (gelu_dstash): the forward's sigmoid serves the
-    // activation and its derivative, and the backward epilogue multiplies instead of evaluating the derivative
-    if (gelu_dstash(e, Tp, f8)) TRY(plb_launch_gemm_nt_gelud(&g, 0, s));
-    else TRY(gemm_nt_any(&g, 1, f8 ? &o1 : nullptr, s));
+    // calls on tile multiples stash gelu_new'(u) in the "u" slot (gelu_dstash): the forward's sigmoid serves the
+    // activation and its derivative, and the backward epilogue multiplies instead of evaluating the derivative. In an
+    // fp8 call gelu(u) itself leaves as its e4m3 image ALONE: nothing reads it in bf16 (FFN output GEMM and weight
+    // gradient take the image)
+    if (dstash) {
+      if (f8 && e->fp8_tn) { g.C2 = nullptr; g.ldc2 = 0; }
+      TRY(gemm_nt_gelud_any(&g, 0, f8 ? &o1 : nullptr, s));
+    } else {
+      TRY(gemm_nt_any(&g, 1, f8 ? &o1 : nullptr, s));
+    }
     if (calib) TRY(plb_launch_amax(gl, 1, (size_t)T, I, I, f8_amax(e, sG), s));
     memset(&g, 0, sizeof(g));
     g.A = gl; g.lda = I; g.B = e->wbf(PLB_FFNO_W); g.ldb = I; g.M = (int)Tp; g.N = H; g.K = I; g.Mstore = (int)Tp;
     g.bias = e->par(PLB_FFNO_B); g.res = a; g.ldr = H; g.C = pre2; g.ldc = H;
     F8Op o2 = {g8, e->at<uint8_t>(e->o_w28), f8_deq(e, sG), f8_deq(e, f8_w(e, F8W_2)), 0};
+    const bool next8 = f8 && l + 1 < L;   // the next application's input image
     if (fuse_f) {  // FFN output + residual + LayerNorm in one launch
       g.C2 = y; g.ldc2 = H;
       ln_fields(e, &g, e->par(PLB_LN2_W), e->par(PLB_LN2_B), e->at<float>(e->o_mean2) + sl * Tp, e->at<float>(e->o_rstd2) + sl * Tp);
-      TRY(plb_launch_gemm_nt_ln(&g, 5, s));
+      if (next8) f8_out(e, &g, x8n, H, f8_site(e, F8_X, l + 1), 0);
+      TRY(gemm_nt_ln_any(&g, 5, f8 ? &o2 : nullptr, s));
     } else {
       TRY(gemm_nt_any(&g, 0, f8 ? &o2 : nullptr, s));
       memset(&ln, 0, sizeof(ln));
       ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.beta = e->par(PLB_LN2_B); ln.eps = e->c.layer_norm_eps;
       ln.y = y; ln.ldy = H; ln.T = T; ln.H = H;
       ln.mean = e->at<float>(e->o_mean2) + sl * Tp; ln.rstd = e->at<float>(e->o_rstd2) + sl * Tp;
-      if (f8 && l + 1 < L) {  // the next application's input image
+      if (next8) {
         const int sN = f8_site(e, F8_X, l + 1);
-        ln.out8 = x8; ln.ld8 = H; ln.q_scale = f8_scale(e, sN); ln.q_amax = f8_amax(e, sN);
+        ln.out8 = x8n; ln.ld8 = H; ln.q_scale = f8_scale(e, sN); ln.q_amax = f8_amax(e, sN);
       }
       TRY(plb_launch_ln_fwd(&ln, s));
     }
@@ -1003,20 +1056,21 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
   }
 
   // ---- layers in reverse --------------------------------------------------------------------------------
-  // fp8 mode: the two FFN dX GEMMs (dU = dpre2 W2, dA = dU W1) read e5m2 images of their gradient operand, written by
-  // the LayerNorm backward and by the gelu-backward epilogue; everything else stays bf16.
-  const bool f8 = e->fp8_on && e->fp8_bwd_ready && fp8_shapes_ok(e, Tp);
-  const bool calib = e->fp8_on && !e->fp8_bwd_ready;
+  // fp8 mode: every dX GEMM reads e5m2 images of its gradient operand — dU = dpre2·W2 and dA = dU·W1 (+ LayerNorm 1
+  // backward), dCtx = dpre1·Wd, dX = dQKV·Wqkv (+ LayerNorm 2 backward of the layer below) — written by the launch that
+  // produces the gradient (fused LayerNorm-backward / gelu-backward epilogues, the attention-backward kernels, the one
+  // standalone LayerNorm backward), one image per layer for the weight-gradient GEMMs at the end.
+  const bool f8 = f8_call(e, Tp, true);
+  const bool calib = e->fp8_on && !f8;
   // ffn.bias gradient from the dU GEMM's epilogue: 2 partial rows per row tile of the kernel that runs it
-  const int du_rows = f8 ? 2 * (int)(Tp / 128) : e->u_is_derivative ? 2 * (int)(Tp / 256) : plb_gemm_nt_colpart_rows((int)Tp, I, H);
+  const int du_rows = e->u_is_derivative ? (f8 ? 2 * (int)(Tp / 128) : 2 * (int)(Tp / 256))
+                                         : (f8 ? 2 * (int)(Tp / 128) : plb_gemm_nt_colpart_rows((int)Tp, I, H));
   bf16_t* da = e->at<bf16_t>(e->o_da);
   bf16_t* dctx = e->at<bf16_t>(e->o_dctx);
-  uint8_t* dp8 = e->at<uint8_t>(e->o_dp8);
-  uint8_t* du8 = e->at<uint8_t>(e->o_du8);
   // LayerNorm backward inside the dX GEMM that produces its output gradient (gemm_ln.hip). Rows of partials per layer:
   // 2 per 128-row tile in the fused form (the one standalone launch left — LayerNorm 2 of the last application, whose
   // output gradient comes from the head — then uses as many blocks), else the LayerNorm kernel's block count.
-  const bool fuse_b = ln_fusable(e, Tp, 2, f8);
+  const bool fuse_b = ln_fusable(e, Tp, 2);
   const int prows = fuse_b ? (int)(2 * Tp / 128) : e->ln_blocks;
   e->part_rows_used = prows;
   for (int l = L - 1; l >= 0; --l) {
@@ -1029,7 +1083,11 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     bf16_t* dpre1 = e->at<bf16_t>(e->o_dpre1) + (int64_t)l * Tp * H;
     bf16_t* du = e->at<bf16_t>(e->o_du) + (int64_t)l * Tp * I;
     bf16_t* dpre2 = e->at<bf16_t>(e->o_dpre2) + (int64_t)l * Tp * H;
-    const int sDP = f8_site(e, F8_DP, l), sDU = f8_site(e, F8_DU, l);
+    uint8_t* dp8 = e->at<uint8_t>(e->o_dp8) + (int64_t)l * Tp * H;
+    uint8_t* du8 = e->at<uint8_t>(e->o_du8) + (int64_t)l * Tp * I;
+    uint8_t* dp18 = e->at<uint8_t>(e->o_dp18) + (int64_t)l * Tp * H;
+    uint8_t* dq8 = e->at<uint8_t>(e->o_dq8) + (int64_t)l * Tp * 3 * H;
+    const int sDP = f8_site(e, F8_DP, l), sDU = f8_site(e, F8_DU, l), sDP1 = f8_site(e, F8_DP1, l), sDQ = f8_site(e, F8_DQ, l);
     PlbLayerNorm ln;
     if (!(fuse_b && l != L - 1)) {  // fused form: the dX GEMM of application l+1 wrote dpre2 of this one (see below)
       memset(&ln, 0, sizeof(ln));
@@ -1046,10 +1104,14 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     g.A = dpre2; g.lda = H; g.B = e->at<bf16_t>(e->o_w2T); g.ldb = H; g.M = (int)Tp; g.N = I; g.K = H; g.Mstore = (int)Tp;
     g.aux = u; g.ldaux = I; g.C = du; g.ldc = I;
     if (du_rows > 0) g.colpart = e->at<float>(e->o_ducol) + (int64_t)l * du_rows * I;
-    if (f8) { g.C8 = du8; g.ldc8 = I; g.q_scale = f8_scale(e, sDU); g.q_amax = f8_amax(e, sDU); g.c8_bf8 = 1; }
+    if (f8) f8_out(e, &g, du8, I, sDU, 1);
     F8Op ou = {dp8, e->at<uint8_t>(e->o_w2T8), f8_deq(e, sDP), f8_deq(e, f8_w(e, F8W_2T)), 1};
-    if (e->u_is_derivative) TRY(plb_launch_gemm_nt_gelud(&g, 1, s));   // what the forward of THIS call stashed
-    else TRY(gemm_nt_any(&g, 2, f8 ? &ou : nullptr, s));
+    if (e->u_is_derivative) {   // what the forward of THIS call stashed; fp8: dU leaves as its e5m2 image alone
+      if (f8 && e->fp8_tn) g.C = nullptr;
+      TRY(gemm_nt_gelud_any(&g, 1, f8 ? &ou : nullptr, s));
+    } else {
+      TRY(gemm_nt_any(&g, 2, f8 ? &ou : nullptr, s));
+    }
     if (calib) TRY(plb_launch_amax(du, 1, (size_t)T, I, I, f8_amax(e, sDU), s));
     // dA = dU · W1 + dpre2
     memset(&g, 0, sizeof(g));
@@ -1062,7 +1124,8 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       g.C = dpre1; g.aux = pre1; g.ldaux = H;
       g.colpart = e->at<float>(e->o_part1) + (int64_t)l * prows * 3 * H;
       ln_fields(e, &g, e->par(PLB_LN1_W), nullptr, e->at<float>(e->o_mean1) + (int64_t)l * Tp, e->at<float>(e->o_rstd1) + (int64_t)l * Tp);
-      TRY(plb_launch_gemm_nt_ln(&g, 6, s));
+      if (f8) f8_out(e, &g, dp18, H, sDP1, 1);
+      TRY(gemm_nt_ln_any(&g, 6, f8 ? &oa : nullptr, s));
     } else {
       TRY(gemm_nt_any(&g, 0, f8 ? &oa : nullptr, s));
       memset(&ln, 0, sizeof(ln));
@@ -1070,25 +1133,37 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       ln.mean = e->at<float>(e->o_mean1) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd1) + (int64_t)l * Tp;
       ln.dy = da; ln.lddy = H; ln.dx = dpre1; ln.lddx = H;
       ln.partials = e->at<float>(e->o_part1) + (int64_t)l * prows * 3 * H; ln.nblocks = prows;
+      if (f8) { ln.out8 = dp18; ln.ld8 = H; ln.q_scale = f8_scale(e, sDP1); ln.q_amax = f8_amax(e, sDP1); }
       TRY(plb_launch_ln_bwd(&ln, s));
     }
+    if (calib) TRY(plb_launch_amax(dpre1, 1, (size_t)T, H, H, f8_amax(e, sDP1), s));
     // dCtx = dpre1 · Wd
     memset(&g, 0, sizeof(g));
     g.A = dpre1; g.lda = H; g.B = e->at<bf16_t>(e->o_wdT); g.ldb = H; g.M = (int)Tp; g.N = H; g.K = H; g.Mstore = (int)Tp;
     g.C = dctx; g.ldc = H;
-    TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+    F8Op oc = {dp18, e->at<uint8_t>(e->o_wdT8), f8_deq(e, sDP1), f8_deq(e, f8_w(e, F8W_DT)), 1};
+    TRY(gemm_nt_any(&g, 0, f8 ? &oc : nullptr, s));
     PlbAttn at;
     memset(&at, 0, sizeof(at));
     at.qkv = qkv; at.ldqkv = 3 * H; at.lengths = lengths; at.B = B; at.S = S; at.NH = e->NH; at.H = H; at.scale = 0.125f;
     at.ctx = ctx; at.ldctx = H; at.lse = e->at<float>(e->o_lse) + (int64_t)l * B * e->NH * S;
     at.dctx = dctx; at.lddctx = H; at.delta = e->at<float>(e->o_delta); at.dqkv = dqkv; at.lddqkv = 3 * H;
     at.colpart = e->at<float>(e->o_qkvcol) + (int64_t)l * (B * ((S + 127) / 128) * 4) * 3 * H; at.colpart_accumulate = 0;
+    if (f8) {   // dQKV leaves as its e5m2 image (alone, once the weight gradient reads images too)
+      at.dqkv8 = dq8; at.lddqkv8 = 3 * H; at.dqkv_scale = f8_scale(e, sDQ); at.dqkv_amax = f8_amax(e, sDQ);
+      if (e->fp8_tn) at.dqkv = nullptr;
+    }
     TRY(plb_launch_attn_bwd(&at, s));
-    if (Tp > T) HIPTRY(hipMemsetAsync(dqkv + (int64_t)T * 3 * H, 0, (size_t)(Tp - T) * 3 * H * 2, s));
+    if (Tp > T) {
+      if (at.dqkv) HIPTRY(hipMemsetAsync(dqkv + (int64_t)T * 3 * H, 0, (size_t)(Tp - T) * 3 * H * 2, s));
+      if (f8) HIPTRY(hipMemsetAsync(dq8 + (int64_t)T * 3 * H, 0, (size_t)(Tp - T) * 3 * H, s));
+    }
+    if (calib) TRY(plb_launch_amax(dqkv, 1, (size_t)T, 3 * H, 3 * H, f8_amax(e, sDQ), s));
     // dX = dQKV · Wqkv + dpre1
     memset(&g, 0, sizeof(g));
     g.A = dqkv; g.lda = 3 * H; g.B = e->at<bf16_t>(e->o_wqkvT); g.ldb = 3 * H; g.M = (int)Tp; g.N = H; g.K = 3 * H;
     g.Mstore = (int)Tp; g.res = dpre1; g.ldr = H; g.C = dy_other; g.ldc = H;
+    F8Op ox = {dq8, e->at<uint8_t>(e->o_wqT8), f8_deq(e, sDQ), f8_deq(e, f8_w(e, F8W_QKVT)), 1};
     if (fuse_b && l > 0) {
       // the gradient of this application's input is the gradient of LayerNorm 2's output of application l-1: that
       // LayerNorm's backward runs here and writes dpre2 of application l-1 directly
@@ -1096,9 +1171,10 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       g.aux = e->at<bf16_t>(e->o_pre2) + (int64_t)(l - 1) * Tp * H; g.ldaux = H;
       g.colpart = e->at<float>(e->o_part2) + (int64_t)(l - 1) * prows * 3 * H;
       ln_fields(e, &g, e->par(PLB_LN2_W), nullptr, e->at<float>(e->o_mean2) + (int64_t)(l - 1) * Tp, e->at<float>(e->o_rstd2) + (int64_t)(l - 1) * Tp);
-      TRY(plb_launch_gemm_nt_ln(&g, 6, s));
+      if (f8) f8_out(e, &g, e->at<uint8_t>(e->o_dp8) + (int64_t)(l - 1) * Tp * H, H, f8_site(e, F8_DP, l - 1), 1);
+      TRY(gemm_nt_ln_any(&g, 6, f8 ? &ox : nullptr, s));
     } else {
-      TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+      TRY(gemm_nt_any(&g, 0, f8 ? &ox : nullptr, s));
     }
     bf16_t* tmp = dy; dy = dy_other; dy_other = tmp;
   }

@@ -6,11 +6,15 @@
 
 static int g_ln_fault_mode = 0, g_ln_fault_launches = 0;
 extern "C" void plb_debug_ln_fault(int mode, int launches) { g_ln_fault_mode = mode; g_ln_fault_launches = launches; }
+extern "C" int plb_ln_fault_take(void) {
+  if (g_ln_fault_launches <= 0) return 0;
+  --g_ln_fault_launches;
+  return g_ln_fault_mode;
+}
 
 extern "C" int plb_launch_gemm_nt_ln(const PlbGemmNT* p_in, int mode, hipStream_t stream) {
   PlbGemmNT q_ = *p_in;
-  q_.ln_fault = 0;
-  if (g_ln_fault_launches > 0) { q_.ln_fault = g_ln_fault_mode; --g_ln_fault_launches; }
+  q_.ln_fault = plb_ln_fault_take();
   const PlbGemmNT* p = &q_;
   if (mode != 5 && mode != 6) return 1;
   if (p->M % 1024 || p->K % 64 || p->M <= 0 || p->N <= 0 || p->K <= 0) return 3;   // 8 XCDs x whole row blocks

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   constexpr int TM = NAH * 128, TN = NBH * 128;
   constexpr int NH = NAH + NBH;  // half-tiles per K-tile, consumed in the order A0 B0 B1 [A1 | B2]
   __shared__ __attribute__((aligned(16))) bf16_t smem[RING * HT];  // 160 KiB: the whole LDS of a CU
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x, lane = tid & 63;   // (re-derived after the K loop in the fp8 build: see the epilogue)
   const int uw = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = uw >> 2, wn = uw & 3;
   const int nbn = p.N / TN;
@@ -161,7 +161,8 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 
   // ---- fragment reads: row-in-half = wm*64 + mi*16 + frow (A) / wn*32 + ni*16 + frow (B);
   // stored chunk = (kk*4 + fq) ^ ((frow>>1)&7)
-  const int frow = lane & 15, fq = lane >> 4, fsw = (frow >> 1) & 7;
+  int frow = lane & 15, fq = lane >> 4;
+  const int fsw = (frow >> 1) & 7;
   const int offA = (wm * 64 + frow) * 64, offB = (wn * 32 + frow) * 64;
   const int c0 = ((0 + fq) ^ fsw) << 3, c1 = ((4 + fq) ^ fsw) << 3;
   // two A and two B fragment buffers (indices are literals everywhere: plain registers). The prefetching
@@ -471,6 +472,14 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
            (double)dc / ((double)dr / 100.0), (double)dr / 100.0 / nk);
   }
 #endif
+  if constexpr (FP8) {
+    // The fp8 K loop is the kernel's register peak (operands travel as 8-register tuples): the lane coordinates the epilogue
+    // needs are re-derived here from mbcnt behind an opaque copy instead of being carried (and spilled) across the loop.
+    lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane));
+    tid = lane + 64 * uw;
+    frow = lane & 15; fq = lane >> 4;
+  }
   // ---- epilogue. Loads are batched per 16-row slab — all bias vectors once, then the residual / aux
   // segments of one slab together — so a slab costs ONE memory round trip instead of one per 16x16
   // tile. bf16 outputs leave through LDS: in MFMA layout one store instruction is 16 rows x 32 B, i.e. 16
@@ -573,9 +582,26 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     // per-launch memset, no epoch argument: the launch can be captured in a graph). The wait is bounded: a time-out
     // raises *ln_err instead of hanging the device.
     static_assert(NAH == 1, "LayerNorm epilogues: 128-row tiles");
+    static_assert(!FP8 || NT_LN_STAGE, "the fp8 LayerNorm forms exist in the staged form only");
+    if constexpr (FP8) {   // fp8 operands: the per-tensor dequantisation first, everything below is the bf16 form's arithmetic
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int nh = 0; nh < NBH; ++nh)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni) acc[0][mi][nh][ni] *= deq;
+    }
+    // fp8 mode: a 1-byte image of the launch's LayerNorm-side output — form 5: e4m3 of C2 = LayerNorm(..), form 6: e5m2
+    // of C = the gradient of the LayerNorm's input — for the fp8 GEMMs that consume it (next projection, weight gradient)
+    // (converted in the final store loop, from the bf16 image rows as they leave: inside the second pass the conversion's
+    // temporaries made the backward form spill)
     constexpr int IMG = TM * OROW * 2;                          // bytes of the output image
     float* const tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + IMG);   // [128 rows][4 wn][2]
     float* const tab2 = tab + 128 * 4 * 2;                                                // [128 rows][2] merged
+    // LEAN (the fp8 backward form): the rows' forward statistics and merged partials are not carried in registers across
+    // the passes (16 per lane) but re-read from LDS tables where they are used: with the fp8 build's register allocation
+    // the 128x384 backward epilogue otherwise spilled six registers
+    constexpr bool LEAN = FP8 && ACT == 6;
     typedef __attribute__((address_space(1))) unsigned long long gu64_t;
     gu64_t* const xq = (gu64_t*)(p.ln_xchg);
     const float invN = 1.0f / (float)p.N;
@@ -603,7 +629,12 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     // the second half travelling under the first half's arithmetic.
     constexpr int R2OFF = IMG + 128 * 4 * 2 * 4 + 128 * 2 * 4;   // bytes
     constexpr int GAMOFF = R2OFF + 64 * OROW * 2;                 // this tile's TN gamma values (form 6), fp32
-    static_assert(GAMOFF + (ACT == 6 ? TN * 4 : 0) <= RING * HT * 2, "staging regions must fit the LDS");
+    constexpr int TAB3OFF = GAMOFF + TN * 4;                      // LEAN: [128 rows][2] = the rows' forward mean | rstd
+    static_assert(GAMOFF + (ACT == 6 ? TN * 4 : 0) + (LEAN ? 1024 : 0) <= RING * HT * 2, "staging regions must fit the LDS");
+    float* const tab3 = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + TAB3OFF);
+    if constexpr (LEAN) {
+      if (tid < TM) { tab3[tid * 2] = p.ln_mean[bm * TM + tid]; tab3[tid * 2 + 1] = p.ln_rstd[bm * TM + tid]; }
+    }
     // form 6 reads gamma per 4-column group inside both passes, and those passes are pinned group by group (registers):
     // from global memory every group waited out an L2 round trip; the tile's gamma row is fetched once, here, beside the
     // operand tiles' DMA
@@ -646,7 +677,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
             if constexpr (ACT == 6) ux[mi][nh][ni] = *(const uint2*)(p.aux + (size_t)m * p.ldaux + ncol0 + nh * 128 + ni * 16);
           }
       }
-      if constexpr (ACT == 6) { rmean[mi] = p.ln_mean[m]; rrstd[mi] = p.ln_rstd[m]; }
+      if constexpr (ACT == 6 && !LEAN) { rmean[mi] = p.ln_mean[m]; rrstd[mi] = p.ln_rstd[m]; }
+      if constexpr (LEAN) {   // (behind the staging barrier above: tab3 is complete)
+        const float2 ms = *(const float2*)&tab3[(wm * 64 + mi * 16 + frow) * 2];
+        rmean[mi] = ms.x; rrstd[mi] = ms.y;
+      }
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     // form 6, staged: the first pass runs per half of the rows (mi 0,1 | mi 2,3) around the residual's two halves
@@ -817,8 +852,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
     // second pass, one 4-column group of the lane at a time (its 4 rows innermost): the three column sums of the backward
     // then need 12 registers instead of 72, which is what lets the pre segments of the first pass stay in registers
     float t0[4], t1[4];
+    if constexpr (!LEAN) {
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) { t0[mi] = tab2[(wm * 64 + mi * 16 + frow) * 2]; t1[mi] = tab2[(wm * 64 + mi * 16 + frow) * 2 + 1]; }
+      for (int mi = 0; mi < 4; ++mi) { t0[mi] = tab2[(wm * 64 + mi * 16 + frow) * 2]; t1[mi] = tab2[(wm * 64 + mi * 16 + frow) * 2 + 1]; }
+    }
+    if constexpr (LEAN) asm volatile("" ::: "memory");   // the first pass's copies of the statistics end here
     // the lane's column offset behind an opaque copy: the second pass forms its addresses afresh from this ONE register
     // instead of carrying the first pass's 64-bit pointers across the hand-off
     int ncol2 = ncol0;
@@ -838,6 +876,11 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
           const int lrow = wm * 64 + mi * 16 + frow;
           const f32x4 x = acc[0][mi][nh][ni];
           f32x4 y;
+          if constexpr (LEAN) {
+            const float2 tt = *(const float2*)&tab2[lrow * 2], ms = *(const float2*)&tab3[lrow * 2];
+            t0[mi] = tt.x; t1[mi] = tt.y; rmean[mi] = ms.x; rrstd[mi] = ms.y;
+            asm volatile("" : "+v"(t0[mi]), "+v"(t1[mi]), "+v"(rmean[mi]), "+v"(rrstd[mi]));   // not hoisted out of the loops
+          }
           if constexpr (ACT == 5) {
             y = f32x4{(x[0] - t0[mi]) * t1[mi] * gz.x + bt.x, (x[1] - t0[mi]) * t1[mi] * gz.y + bt.y,
                       (x[2] - t0[mi]) * t1[mi] * gz.z + bt.z, (x[3] - t0[mi]) * t1[mi] * gz.w + bt.w};
@@ -857,6 +900,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
           uint2 o; o.x = pack_bf2(y[0], y[1]); o.y = pack_bf2(y[2], y[3]);
           *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = o;
           if (ACT == 6 && bm * TM + lrow < p.Mstore) cs += f32x4{bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};
+
         }
         if constexpr (ACT == 6 && !(NT_DBG & 64)) {   // (NT_DBG 64: timing build without these outputs)
           // dgamma | dbeta | column sums of dx over this wave's 64 rows: one partial row per (row tile, wm)
@@ -885,6 +929,33 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
         const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
         if (r < rows_ok) OUT_STORE((obase + (size_t)r * ldo + cc * 8), v);
       }
+      if constexpr (FP8) {
+        if (p.C8) {   // the same rows once more, as bytes: 8 values of the bf16 image -> 8 bytes per lane
+          const float qs8 = p.q_scale[0];
+          const bool bf8o = p.c8_bf8 != 0;
+          float amax8 = 0.f;
+          unsigned char* const qbase = p.C8 + (size_t)(bm * TM) * p.ldc8 + bn * TN;
+#pragma unroll 4
+          for (int c = tid; c < TM * CPR; c += 512) {
+            const int r = c / CPR, cc = c - r * CPR;
+            const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
+            if (r < rows_ok) {
+              const float f0 = bf_lo(v.x), f1 = bf_hi(v.x), f2 = bf_lo(v.y), f3 = bf_hi(v.y);
+              const float f4 = bf_lo(v.z), f5 = bf_hi(v.z), f6 = bf_lo(v.w), f7 = bf_hi(v.w);
+              uint2 w;
+              w.x = pack_fp8x4(f0 * qs8, f1 * qs8, f2 * qs8, f3 * qs8, bf8o);
+              w.y = pack_fp8x4(f4 * qs8, f5 * qs8, f6 * qs8, f7 * qs8, bf8o);
+              *(uint2*)(qbase + (size_t)r * p.ldc8 + cc * 8) = w;
+              amax8 = fmaxf(amax8, fmaxf(fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(f3))),
+                                         fmaxf(fmaxf(fabsf(f4), fabsf(f5)), fmaxf(fabsf(f6), fabsf(f7)))));
+            }
+          }
+          if (p.q_amax) {
+            amax8 = wave_max(amax8);
+            if (lane == 0) atomic_max_abs(p.q_amax, amax8, blockIdx.x * 8 + uw);
+          }
+        }
+      }
     }
 #if NT_DBG & 32
     ls_[4] = __builtin_amdgcn_s_memrealtime();
@@ -912,6 +983,8 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
   const bool want8 = FP8 && p.C8 != nullptr;
   const float qs = want8 ? p.q_scale[0] : 1.0f;
   float amax = 0.f;
+  // fp8 mode: an output that only fp8 GEMMs consume (gelu(u), dU) leaves as its 1-byte image alone — no bf16 image
+  const bool want16 = !FP8 || (ACT == 7 ? p.C2 : p.C) != nullptr;
 #pragma unroll
   for (int mh = 0; mh < NAH; ++mh)
 #pragma unroll
@@ -1021,16 +1094,17 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
               else   // read once, a backward pass later: non-temporal like the other outputs of the gelu forms
                 __builtin_nontemporal_store(u32x4nt{dpair.x, dpair.y, o.x, o.y},
                     (u32x4nt*)(lane_stash + ((size_t)(bm * nbn + bn) * (NAH * 4 * NBH) + (mh * 4 + mi) * NBH + nh) * 512 + tid));
-              *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = gpk;
+              if (want16) *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = gpk;
             } else {
-              *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = o;
+              if (want16) *(uint2*)&smem[lrow * OROW + nh * 128 + wn * 32 + ni * 16 + fq * 4] = o;
             }
             if (ACT == 1) keep[mh][mi][nh][ni] = o;
             v = f32x4{bf_lo(o.x), bf_hi(o.x), bf_lo(o.y), bf_hi(o.y)};  // the values as stored
             if constexpr (FP8 && ACT != 1) {
-              if (want8) {
-                k8[mh][mi][nh][ni] = pack_fp8x4(v[0] * qs, v[1] * qs, v[2] * qs, v[3] * qs, p.c8_bf8 != 0);
-                if (st) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+              if (want8) {   // form 7: the image is of gelu(u) (what the bf16 path's FFN output GEMM reads), not of the stash
+                const f32x4 z = ACT == 7 ? f32x4{bf_lo(gpk.x), bf_hi(gpk.x), bf_lo(gpk.y), bf_hi(gpk.y)} : v;
+                k8[mh][mi][nh][ni] = pack_fp8x4(z[0] * qs, z[1] * qs, z[2] * qs, z[3] * qs, p.c8_bf8 != 0);
+                if (st) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(z[0]), fabsf(z[1])), fmaxf(fabsf(z[2]), fabsf(z[3]))));
               }
             }
           }
@@ -1046,11 +1120,13 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
 #if NT_DBG & 32
     st_[3] = __builtin_amdgcn_s_memrealtime();
 #endif
+    if (want16) {
 #pragma unroll 4
-    for (int c = tid; c < TM * CPR; c += 512) {
-      const int r = c / CPR, cc = c - r * CPR;
-      const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
-      if (r < rows_ok) OUT_STORE((cbase + (size_t)r * ldimg + cc * 8), v);
+      for (int c = tid; c < TM * CPR; c += 512) {
+        const int r = c / CPR, cc = c - r * CPR;
+        const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
+        if (r < rows_ok) OUT_STORE((cbase + (size_t)r * ldimg + cc * 8), v);
+      }
     }
     if (ACT == 1) {  // gelu forward: C keeps the bf16 pre-activation u, C2 = gelu_new(u)
       __syncthreads();

@@ -15,6 +15,7 @@ enum PlbKernelClass {
   PLB_K_EMBED_BWD, PLB_K_COLSUM, PLB_K_REDUCE, PLB_K_ROWS, PLB_K_CE, PLB_K_ADAMW, PLB_K_CAST, PLB_K_TOKEN_CE, PLB_K_GEMM_NT_CE, PLB_K_GEMM_NT_SMALL, PLB_K_FP8, PLB_K_ATTN_BWD,
   PLB_K_GEMM_NT_FP8, PLB_K_GEMM_NT_GELU_FP8, PLB_K_GEMM_NT_GELUBWD_FP8,  // the fp8 launches: priced against the fp8 MFMA peak
   PLB_K_GEMM_NT_LNFWD, PLB_K_GEMM_NT_LNBWD,  // GEMM + LayerNorm epilogue (gemm_ln.hip)
+  PLB_K_GEMM_NT_LNFWD_FP8, PLB_K_GEMM_NT_LNBWD_FP8, PLB_K_GEMM_TN_FP8,  // fp8 forms of the same, and of the weight-gradient GEMM
   PLB_K_NCLASS
 };
 int plb_prof_begin(int cls, hipStream_t s, double flops, double bytes);
@@ -73,6 +74,13 @@ int plb_launch_gemm_nt_gelud(const PlbGemmNT* p, int backward, hipStream_t strea
 // fp8 (e4m3 weights; e4m3 or e5m2 activations / gradients) form of plb_launch_gemm_nt on the pipeline kernel.
 // Returns 3 when the shape has no big-tile form (the caller then uses the bf16 GEMM).
 int plb_launch_gemm_nt_fp8(const PlbGemmNT* p, int act, int a_bf8, hipStream_t stream);
+// fp8-operand forms of plb_launch_gemm_nt_ln (modes 5 / 6) and plb_launch_gemm_nt_gelud (gemm_fp8_ln.hip). A / B are 1-byte
+// images, deq_a / deq_b their dequantisation factors; C8 (+ q_scale, q_amax, c8_bf8) is the 1-byte image of the output the
+// next fp8 GEMMs read — mode 5: of C2, mode 6: of C, gelu forward: of C2 = gelu(u), gelu backward: of C. In the gelu forms the
+// bf16 image (C2 / C) may be NULL: only the fp8 image leaves. Same shape rules as the bf16 forms, K % 128 == 0; 3 = no form.
+int plb_launch_gemm_nt_fp8_ln(const PlbGemmNT* p, int mode, int a_bf8, hipStream_t stream);
+int plb_launch_gemm_nt_fp8_gelud(const PlbGemmNT* p, int backward, int a_bf8, hipStream_t stream);
+int plb_ln_fault_take(void);  // fault injection state shared by the LayerNorm launchers (plb_debug_ln_fault)
 int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream);
 int plb_gemm_nt_colpart_rows(int M, int N, int K);  // rows of colpart written for this shape (0: unsupported)
 // Tuning / test hooks (not part of include/plbert.h): force a tile (0 = per-shape policy; 128, 256, 384, 1256 =
@@ -168,6 +176,11 @@ typedef struct {
   bf16_t* dqkv; int lddqkv;     // [T,3H]
   float* colpart;               // backward, optional: [B * ceil(S/128) * 4][3H] column sums of dqkv per (sample, 128-row tile, wave)
   int colpart_accumulate;       // add to colpart instead of overwriting (sum over the applications of the shared layer)
+  // fp8 mode, optional 1-byte images of the outputs for the fp8 GEMMs that consume them (the values as rounded to bf16,
+  // times *scale, saturated): forward ctx8 = e4m3(ctx) [T,H]; backward dqkv8 = e5m2(dqkv) [T,3H]. amax: the site (64 words,
+  // common.h) that collects max |value| for the next step's scale. dqkv may be NULL when dqkv8 is given.
+  uint8_t* ctx8; int ldctx8; const float* ctx_scale; float* ctx_amax;
+  uint8_t* dqkv8; int lddqkv8; const float* dqkv_scale; float* dqkv_amax;
 } PlbAttn;
 int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream);
 // Default: the two-kernel form, dq (+delta) then dk,dv. plb_set_attn_bwd_fused(1) / PLBERT_ATTN_BWD=fused: ONE kernel for

@@ -160,3 +160,186 @@ def test_fp8_training_descends_with_the_bf16_run():
     assert all(np.isfinite(lf)) and lf[-1] < lf[0] - 0.05                    # it learns
     assert max(abs(a - b) / b for a, b in zip(lf, lb)) < 3e-2, (lf, lb)      # and tracks the bf16 run
     assert not torch.isnan(tf.engine.params).any()
+
+
+# ---- fp8 forms of the fused epilogues (csrc/gemm_fp8_ln.hip): LayerNorm in the GEMM, gelu-derivative stash -----------
+# Operands are quantised with POWER-OF-TWO scales, so the dequantised values are exact in bf16: the bf16 forms of the same
+# epilogues (pinned against torch in tests/test_gpu_gemm_ln.py) then compute the very same products, and the only
+# difference left is the accumulation order inside the MFMAs.
+def _q2(x, bf8, headroom=1.0):
+    import math
+    mx = 57344.0 if bf8 else 448.0
+    scale = 2.0 ** math.floor(math.log2(mx * headroom / float(x.abs().max())))
+    q, d = _q(x, scale, bf8)
+    return q, d.to(torch.bfloat16), scale
+
+
+class _F8Ln:
+    def __init__(self, M, N, K, bf8, seed):
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        A = torch.randn(M, K, device=DEV, generator=g) * (0.02 if bf8 else 1.0)
+        W = torch.randn(N, K, device=DEV, generator=g) * K ** -0.5
+        self.A8, self.Ad, sa = _q2(A, bf8)
+        self.W8, self.Wd, sw = _q2(W, False)
+        self.deq = torch.tensor([1.0 / sa, 1.0 / sw], device=DEV)
+        self.M, self.N, self.K, self.bf8 = M, N, K, bf8
+        self.bias = torch.randn(N, device=DEV, generator=g) * 0.3
+        self.res = (torch.randn(M, N, device=DEV, generator=g) * (0.05 if bf8 else 1.0)).to(torch.bfloat16)
+        self.gamma = 1.0 + 0.3 * torch.randn(N, device=DEV, generator=g)
+        self.beta = 0.2 * torch.randn(N, device=DEV, generator=g)
+        nbn = N // (384 if N % 384 == 0 else 256)
+        self.xchg = torch.zeros(M // 128 * nbn * nbn * 128 * 2, dtype=torch.int64, device=DEV)
+        self.err = torch.zeros(2, dtype=torch.int32, device=DEV)
+        self.mean = torch.zeros(M, device=DEV)
+        self.rstd = torch.zeros(M, device=DEV)
+        self.qs = torch.tensor([4.0 if not bf8 else 2.0 ** 14], device=DEV)
+        self.amax = torch.zeros(64 * 16, device=DEV)
+
+    def params(self, fp8):
+        p = _lib.PlbGemmNT()
+        if fp8:
+            p.A, p.B = self.A8.view(torch.uint8).data_ptr(), self.W8.view(torch.uint8).data_ptr()
+            p.deq_a, p.deq_b = self.deq.data_ptr(), self.deq.data_ptr() + 4
+        else:
+            p.A, p.B = self.Ad.data_ptr(), self.Wd.data_ptr()
+        p.lda, p.ldb, p.M, p.N, p.K, p.Mstore = self.K, self.K, self.M, self.N, self.K, self.M - 5
+        p.ln_gamma, p.ln_beta, p.ln_mean, p.ln_rstd = self.gamma.data_ptr(), self.beta.data_ptr(), self.mean.data_ptr(), self.rstd.data_ptr()
+        p.ln_eps, p.ln_xchg, p.ln_err = 1e-12, self.xchg.data_ptr(), self.err.data_ptr()
+        return p
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 768), (2048, 768, 2048), (1024, 1024, 1024), (1024, 1024, 4096)])
+def test_fp8_layernorm_forward_form_against_the_bf16_form(M, N, K):
+    L = _lib.lib()
+    t = _F8Ln(M, N, K, False, seed=M + N + K)
+    outs = []
+    for fp8 in (False, True):
+        pre = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        y = torch.zeros_like(pre)
+        img = torch.full((M, N), 0x55, dtype=torch.uint8, device=DEV)
+        p = t.params(fp8)
+        p.bias, p.res, p.ldr = t.bias.data_ptr(), t.res.data_ptr(), N
+        p.C, p.ldc, p.C2, p.ldc2 = pre.data_ptr(), N, y.data_ptr(), N
+        if fp8:
+            p.C8, p.ldc8, p.q_scale, p.q_amax, p.c8_bf8 = img.data_ptr(), N, t.qs.data_ptr(), t.amax.data_ptr(), 0
+            assert L.plb_launch_gemm_nt_fp8_ln(C.byref(p), 5, 0, stream()) == 0
+        else:
+            assert L.plb_launch_gemm_nt_ln(C.byref(p), 5, stream()) == 0
+        torch.cuda.synchronize()
+        outs.append((pre, y, t.mean.clone(), t.rstd.clone(), img))
+    (pre0, y0, m0, r0, _), (pre1, y1, m1, r1, img) = outs
+    rows = slice(0, M - 5)
+    assert rel_l2(pre1[rows].float(), pre0[rows].float()) < 2e-3           # same products, other accumulation order, bf16 store
+    assert rel_l2(y1[rows].float(), y0[rows].float()) < 3e-3
+    assert (m1[rows] - m0[rows]).abs().max() < 2e-3 and ((r1[rows] - r0[rows]) / r0[rows]).abs().max() < 2e-3
+    q = img.view(torch.float8_e4m3fn).float() / 4.0
+    assert rel_l2(q[rows], y1[rows].float()) < 4e-2                          # the image is the stored bf16 row, 3 mantissa bits
+    assert (q[rows] - y1[rows].float()).abs().max() <= 2.0 ** -4 * float(y1[rows].float().abs().max()) + 1e-6
+    assert (img[M - 5:] == 0x55).all() and (y1[M - 5:] == 0).all()           # rows >= Mstore: untouched
+    assert abs(float(t.amax.max()) - float(y1[rows].float().abs().max())) < 1e-6
+    assert int(t.err[0].item()) == 0 and int(t.xchg.abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 768, 2048), (2048, 768, 2304), (1024, 1024, 4096), (1024, 1024, 3072)])
+def test_fp8_layernorm_backward_form_against_the_bf16_form(M, N, K):
+    """Operand A is a gradient: e5m2 image."""
+    L = _lib.lib()
+    t = _F8Ln(M, N, K, True, seed=M + N + K + 1)
+    pre = (torch.randn(M, N, device=DEV, generator=torch.Generator(device=DEV).manual_seed(5))).to(torch.bfloat16)
+    x = pre.float()
+    t.mean.copy_(x.mean(1)); t.rstd.copy_((x.var(1, unbiased=False) + 1e-12).rsqrt())
+    outs = []
+    for fp8 in (False, True):
+        dx = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        colp = torch.full((2 * M // 128, 3, N), 9.0, device=DEV)
+        img = torch.full((M, N), 0x55, dtype=torch.uint8, device=DEV)
+        p = t.params(fp8)
+        p.res, p.ldr, p.aux, p.ldaux = t.res.data_ptr(), N, pre.data_ptr(), N
+        p.C, p.ldc, p.colpart = dx.data_ptr(), N, colp.data_ptr()
+        if fp8:
+            p.C8, p.ldc8, p.q_scale, p.q_amax, p.c8_bf8 = img.data_ptr(), N, t.qs.data_ptr(), t.amax.data_ptr(), 1
+            assert L.plb_launch_gemm_nt_fp8_ln(C.byref(p), 6, 1, stream()) == 0
+        else:
+            assert L.plb_launch_gemm_nt_ln(C.byref(p), 6, stream()) == 0
+        torch.cuda.synchronize()
+        outs.append((dx, colp, img))
+    (dx0, c0, _), (dx1, c1, img) = outs
+    rows = slice(0, M - 5)
+    assert rel_l2(dx1[rows].float(), dx0[rows].float()) < 4e-3
+    for k in range(3):
+        assert rel_l2(c1.double().sum(0)[k], c0.double().sum(0)[k]) < 2e-3
+    q = img.view(torch.float8_e5m2).float() / float(t.qs.item())
+    assert rel_l2(q[rows], dx1[rows].float()) < 8e-2                         # 2 mantissa bits
+    assert (img[M - 5:] == 0x55).all()
+    assert abs(float(t.amax.max()) - float(dx1[rows].float().abs().max())) < 1e-6
+    assert int(t.err[0].item()) == 0 and int(t.xchg.abs().sum().item()) == 0
+
+
+@pytest.mark.parametrize("M,N,K,with16", [(256, 2048, 768, True), (1024, 2048, 768, False), (384, 4096, 1024, True)])
+def test_fp8_gelu_stash_forms_forward_then_backward(M, N, K, with16):
+    """FFN up-projection + gelu_new with the derivative stashed, and the matching backward, on fp8 operands. The stash is
+    private to the pair of launches (lane layout of the 128x256 tile): it is checked through the backward's result.
+    with16 = False: gelu(u) and dU leave as their 1-byte images alone (what an fp8 training call does)."""
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    A8, Ad, sa = _q2(torch.randn(M, K, device=DEV, generator=g), False)
+    W8, Wd, sw = _q2(torch.randn(N, K, device=DEV, generator=g) * K ** -0.5, False)
+    bias = torch.randn(N, device=DEV, generator=g) * 0.3
+    deq = torch.tensor([1.0 / sa, 1.0 / sw], device=DEV)
+    stash = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    gl = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    g8 = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
+    qs = torch.tensor([16.0], device=DEV)
+    amax = torch.zeros(64 * 16, device=DEV)
+    p = _lib.PlbGemmNT()
+    p.A, p.lda, p.B, p.ldb = A8.view(torch.uint8).data_ptr(), K, W8.view(torch.uint8).data_ptr(), K
+    p.M, p.N, p.K, p.Mstore = M, N, K, M
+    p.deq_a, p.deq_b, p.bias = deq.data_ptr(), deq.data_ptr() + 4, bias.data_ptr()
+    p.C, p.ldc = stash.data_ptr(), N
+    if with16:
+        p.C2, p.ldc2 = gl.data_ptr(), N
+    p.C8, p.ldc8, p.q_scale, p.q_amax, p.c8_bf8 = g8.data_ptr(), N, qs.data_ptr(), amax.data_ptr(), 0
+    assert L.plb_launch_gemm_nt_fp8_gelud(C.byref(p), 0, 0, stream()) == 0
+    torch.cuda.synchronize()
+    u = (Ad.double() @ Wd.double().T + bias.double()).float().requires_grad_(True)
+    ref_g = torch.nn.functional.gelu(u, approximate="tanh")
+    q = g8.view(torch.float8_e4m3fn).float() / 16.0
+    assert rel_l2(q, ref_g.detach()) < 4e-2
+    if with16:
+        assert rel_l2(gl.float(), ref_g.detach()) < 4e-3
+        assert rel_l2(q, gl.float()) < 4e-2
+        assert abs(float(amax.max()) - float(gl.float().abs().max())) < 1e-6
+    else:
+        assert (gl == 7.0).all()                                             # no bf16 image was written
+    # backward: dU = (dY·W2ᵀ) ∘ gelu'(u) with a gradient operand in e5m2
+    K2 = 768 if K == 768 else 1024
+    D8, Dd, sd = _q2(torch.randn(M, K2, device=DEV, generator=g) * 0.01, True)
+    V8, Vd, sv = _q2(torch.randn(N, K2, device=DEV, generator=g) * K2 ** -0.5, False)
+    deq2 = torch.tensor([1.0 / sd, 1.0 / sv], device=DEV)
+    du = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+    du8 = torch.zeros(M, N, dtype=torch.uint8, device=DEV)
+    colp = torch.zeros(2 * (M // 128), N, device=DEV)
+    qs2 = torch.tensor([2.0 ** 16], device=DEV)
+    amax2 = torch.zeros(64 * 16, device=DEV)
+    p2 = _lib.PlbGemmNT()
+    p2.A, p2.lda, p2.B, p2.ldb = D8.view(torch.uint8).data_ptr(), K2, V8.view(torch.uint8).data_ptr(), K2
+    p2.M, p2.N, p2.K, p2.Mstore = M, N, K2, M
+    p2.deq_a, p2.deq_b = deq2.data_ptr(), deq2.data_ptr() + 4
+    p2.aux, p2.ldaux, p2.colpart = stash.data_ptr(), N, colp.data_ptr()
+    if with16:
+        p2.C, p2.ldc = du.data_ptr(), N
+    p2.C8, p2.ldc8, p2.q_scale, p2.q_amax, p2.c8_bf8 = du8.data_ptr(), N, qs2.data_ptr(), amax2.data_ptr(), 1
+    assert L.plb_launch_gemm_nt_fp8_gelud(C.byref(p2), 1, 1, stream()) == 0
+    torch.cuda.synchronize()
+    dg = (Dd.double() @ Vd.double().T).float()
+    ref_g.backward(dg)
+    want = u.grad
+    got8 = du8.view(torch.float8_e5m2).float() / 2.0 ** 16
+    assert rel_l2(got8, want) < 8e-2
+    if with16:
+        assert rel_l2(du.float(), want) < 8e-3                              # the derivative went through one bf16 rounding
+        assert rel_l2(colp.sum(0), du.float().sum(0)) < 1e-4
+        assert abs(float(amax2.max()) - float(du.float().abs().max())) < 1e-9
+    else:
+        assert (du == 7.0).all()
+        assert rel_l2(colp.sum(0), want.sum(0)) < 2e-2
