@@ -92,7 +92,7 @@ class PlbGemmTN(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("lda", C.c_int), ("Ncols", C.c_int), ("B", C.c_void_p), ("ldb", C.c_int),
         ("Mtot", C.c_int), ("N", C.c_int), ("K", C.c_int), ("rows_per_split", C.c_int), ("splits", C.c_int),
-        ("slab", C.c_void_p),
+        ("slab", C.c_void_p), ("deq_a", C.c_void_p), ("deq_b", C.c_void_p),
     ]
 
 
@@ -238,6 +238,8 @@ def lib():
     L.plb_launch_gemm_tn.argtypes = [C.POINTER(PlbGemmTN), vp]
     L.plb_launch_gemm_tn_big.restype = C.c_int
     L.plb_launch_gemm_tn_big.argtypes = [C.POINTER(PlbGemmTN), vp]
+    L.plb_launch_gemm_tn_fp8.restype = C.c_int
+    L.plb_launch_gemm_tn_fp8.argtypes = [C.POINTER(PlbGemmTN), vp]
     L.plb_launch_reduce_slabs.restype = C.c_int
     L.plb_launch_reduce_slabs.argtypes = [vp, C.c_int, C.c_size_t, vp, C.c_int, vp]
     L.plb_launch_attn_fwd.restype = C.c_int

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libplbert_hip.so")
-SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_fp8.hip", "gemm_fp8_ln.hip", "gemm_ln.hip", "attn.hip", "attn_bwd_fused.hip", "rowops.hip", "mask.hip", "engine.cpp"]
+SOURCES = ["gemm.hip", "gemm_big.hip", "gemm_fp8.hip", "gemm_fp8_ln.hip", "gemm_tn_fp8.hip", "gemm_ln.hip", "attn.hip", "attn_bwd_fused.hip", "rowops.hip", "mask.hip", "engine.cpp"]
 HEADERS = ["common.h", "plbert_kernels.h", "gemm_epilogue.h", "gemm_nt_pipeline.h", "attn_common.h", os.path.join("..", "..", "include", "plbert.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # Per-source flags. attn_bwd_fused.hip is a one-wave-per-SIMD kernel with the whole 512-entry register file: by default

@@ -190,7 +190,8 @@ struct PlbEngine {
   // fp8 mode (plb_set_fp8): transient 1-byte images of the fp8 GEMMs' activation / gradient operands, fp8 weight copies
   // and the per-(site, layer) delayed-scaling state [amax | scale | deq] (+ one entry per weight copy)
   bool fp8_on = false, fp8_ready = false, fp8_bwd_ready = false, fp8_wstale = true;
-  bool fp8_tn = false;          // the weight-gradient GEMMs run on the 1-byte images too (PLBERT_FP8_TN=0: bf16 operands)
+  bool fp8_tn = true;           // fp8 calls run the weight-gradient GEMMs on the 1-byte images too (PLBERT_FP8_TN=0: bf16 operands)
+  bool tn8_call = false;        // ... decided per training call by its forward (shapes), read by its backward
   // per-layer 1-byte images [Ls][Tp][width] of every GEMM operand that is an activation (e4m3: layer input x, context,
   // attention-block output a, gelu output g) or a gradient (e5m2: dpre2, dU, dpre1, dQKV): read by the next NT GEMM and,
   // all layers at once, by the token-major weight-gradient GEMMs
@@ -317,6 +318,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
     e->ln_fuse = !strcmp(v, "off") ? 0 : !strcmp(v, "fwd") ? 1 : !strcmp(v, "bwd") ? 2 : 3;
   e->part_rows = e->ln_blocks > (int)(2 * Tp / 128) ? e->ln_blocks : (int)(2 * Tp / 128);
   if (const char* v = getenv("PLBERT_GELU_STASH")) e->gelu_dstash_on = strcmp(v, "u") != 0;
+  if (const char* v = getenv("PLBERT_FP8_TN")) e->fp8_tn = strcmp(v, "0") != 0;
   Carve cv;
   // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes
   e->o_wbf = cv.take((e->ptotal + 256 * (H > I ? H : I)) * 2);
@@ -542,7 +544,7 @@ static int fp8_quantize_weights(PlbEngine* e, hipStream_t s) {
     if (!w.src) continue;
     TRY(plb_launch_amax(w.src, w.bf16, (size_t)w.rows, w.cols, w.cols, f8_amax(e, f8_w(e, w.w)), s));
   }
-  TRY(plb_launch_fp8_scales(f8_amax(e, f8_w(e, 0)), f8_scale(e, f8_w(e, 0)), f8_deq(e, f8_w(e, 0)), F8W_N, 448.f, s));
+  TRY(plb_launch_fp8_scales(f8_amax(e, f8_w(e, 0)), f8_scale(e, f8_w(e, 0)), f8_deq(e, f8_w(e, 0)), F8W_N, 448.f, 1, s));
   for (auto& w : ws) {
     if (!w.src) continue;
     TRY(plb_launch_quantize(w.src, w.bf16, (size_t)w.rows, w.cols, w.cols, f8_scale(e, f8_w(e, w.w)), e->at<uint8_t>(w.dst),
@@ -554,8 +556,10 @@ static int fp8_quantize_weights(PlbEngine* e, hipStream_t s) {
 // end of a call in fp8 mode: this call's maxima become the next call's scales (delayed scaling, history 1)
 static int fp8_update_scales(PlbEngine* e, hipStream_t s) {
   const int L = e->L;
-  TRY(plb_launch_fp8_scales(f8_amax(e, 0), f8_scale(e, 0), f8_deq(e, 0), 4 * L, 448.f, s));                // X, A, G, C: e4m3
-  TRY(plb_launch_fp8_scales(f8_amax(e, 4 * L), f8_scale(e, 4 * L), f8_deq(e, 4 * L), 4 * L, 57344.f, s));  // DP, DU, DP1, DQ: e5m2
+  // One scale per SITE, shared by its L applications (their maxima are recorded per application): the weight-gradient
+  // GEMMs sum the products of two images over all applications under one dequantisation factor.
+  TRY(plb_launch_fp8_scales(f8_amax(e, 0), f8_scale(e, 0), f8_deq(e, 0), 4 * L, 448.f, L, s));                // X, A, G, C: e4m3
+  TRY(plb_launch_fp8_scales(f8_amax(e, 4 * L), f8_scale(e, 4 * L), f8_deq(e, 4 * L), 4 * L, 57344.f, L, s));  // DP, DU, DP1, DQ: e5m2
   return 0;
 }
 
@@ -678,6 +682,7 @@ static void ln_fields(const PlbEngine* e, PlbGemmNT* g, const float* gamma, cons
 // attention kernel; the standalone LayerNorm kernels on shapes without a fused form), one image per layer in a training
 // call: the weight-gradient GEMMs read them all at the end of the backward. A calibration call (the first after
 // plb_set_fp8, and a training call whose gradient sites have not been seen yet) runs in bf16 and only records the maxima.
+static bool tn8_ok(const PlbEngine* e, int64_t Mtot);
 static bool f8_call(const PlbEngine* e, int64_t Tp, bool train) {
   return e->fp8_on && e->fp8_ready && (!train || e->fp8_bwd_ready) && fp8_shapes_ok(e, Tp);
 }
@@ -709,6 +714,10 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
   }
   const bool fuse_f = ln_fusable(e, Tp, 1);
   const bool dstash = gelu_dstash(e, Tp, f8);
+  // do the weight-gradient GEMMs of this call read the 1-byte images? Then gelu(u), dU and dQKV leave as images alone.
+  // (Needs the derivative stash: forms 1 / 2 always write their bf16 outputs.)
+  if (stash) e->tn8_call = f8 && e->fp8_tn && dstash && tn8_ok(e, (int64_t)L * Tp);
+  const bool tn8 = stash && e->tn8_call;
 
   for (int l = 0; l < L; ++l) {
     const int64_t sl = stash ? l : 0;
@@ -775,7 +784,7 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     // fp8 call gelu(u) itself leaves as its e4m3 image ALONE: nothing reads it in bf16 (FFN output GEMM and weight
     // gradient take the image)
     if (dstash) {
-      if (f8 && e->fp8_tn) { g.C2 = nullptr; g.ldc2 = 0; }
+      if (tn8) { g.C2 = nullptr; g.ldc2 = 0; }
       TRY(gemm_nt_gelud_any(&g, 0, f8 ? &o1 : nullptr, s));
     } else {
       TRY(gemm_nt_any(&g, 1, f8 ? &o1 : nullptr, s));
@@ -866,6 +875,30 @@ static int weight_grad(PlbEngine* e, const bf16_t* A, int lda, int Ncols, const 
   }
   if (!direct) TRY(plb_launch_reduce_slabs(t.slab, t.splits, (size_t)N * K, out, 0, s));
   return 0;
+}
+
+// The same on the per-layer 1-byte images of an fp8 call: A8 = e5m2 gradient image [Mtot, N], B8 = e4m3 activation image
+// [Mtot, K] (row strides = widths in bytes), one dequantisation factor per operand site (shared by the L applications).
+static int weight_grad8(PlbEngine* e, const uint8_t* A8, const uint8_t* B8, int64_t Mtot, int N, int K, int site_a, int site_b,
+                        float* out, hipStream_t s) {
+  PlbGemmTN t;
+  memset(&t, 0, sizeof(t));
+  t.A = reinterpret_cast<const bf16_t*>(A8); t.lda = N; t.Ncols = N; t.B = reinterpret_cast<const bf16_t*>(B8); t.ldb = K;
+  t.Mtot = (int)Mtot; t.N = N; t.K = K;
+  t.splits = tn_splits(Mtot, N, K, &t.rows_per_split);
+  t.rows_per_split = (int)rup(t.rows_per_split, 128);   // K-tiles of 128 tokens
+  t.splits = (int)((Mtot + t.rows_per_split - 1) / t.rows_per_split);
+  if ((int64_t)t.splits * N * K > e->slab_floats) return fail("weight_grad8: slab too small");
+  t.slab = e->at<float>(e->o_slab);
+  t.deq_a = f8_deq(e, f8_site(e, site_a, 0)); t.deq_b = f8_deq(e, f8_site(e, site_b, 0));
+  const int tok = plb_prof_begin(PLB_K_GEMM_TN_FP8, s, 2.0 * (double)Mtot * N * K, 0.0);
+  TRY(plb_launch_gemm_tn_fp8(&t, s));
+  plb_prof_end(tok, s);
+  TRY(plb_launch_reduce_slabs(t.slab, t.splits, (size_t)N * K, out, 0, s));
+  return 0;
+}
+static bool tn8_ok(const PlbEngine* e, int64_t Mtot) {
+  return Mtot % 128 == 0 && e->H % 256 == 0 && e->I % 256 == 0 && Mtot >= 8192;
 }
 
 static int backward_tail(PlbEngine* e, const int64_t* masked_ids, bf16_t* dy, int B, int S, int du_rows, hipStream_t s);
@@ -1107,7 +1140,7 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     if (f8) f8_out(e, &g, du8, I, sDU, 1);
     F8Op ou = {dp8, e->at<uint8_t>(e->o_w2T8), f8_deq(e, sDP), f8_deq(e, f8_w(e, F8W_2T)), 1};
     if (e->u_is_derivative) {   // what the forward of THIS call stashed; fp8: dU leaves as its e5m2 image alone
-      if (f8 && e->fp8_tn) g.C = nullptr;
+      if (e->tn8_call) g.C = nullptr;
       TRY(gemm_nt_gelud_any(&g, 1, f8 ? &ou : nullptr, s));
     } else {
       TRY(gemm_nt_any(&g, 2, f8 ? &ou : nullptr, s));
@@ -1151,7 +1184,7 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     at.colpart = e->at<float>(e->o_qkvcol) + (int64_t)l * (B * ((S + 127) / 128) * 4) * 3 * H; at.colpart_accumulate = 0;
     if (f8) {   // dQKV leaves as its e5m2 image (alone, once the weight gradient reads images too)
       at.dqkv8 = dq8; at.lddqkv8 = 3 * H; at.dqkv_scale = f8_scale(e, sDQ); at.dqkv_amax = f8_amax(e, sDQ);
-      if (e->fp8_tn) at.dqkv = nullptr;
+      if (e->tn8_call) at.dqkv = nullptr;
     }
     TRY(plb_launch_attn_bwd(&at, s));
     if (Tp > T) {
@@ -1252,13 +1285,18 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   // tensors between the weights in the flat order (biases, LayerNorm, embeddings) come from the side stream, which needs
   // about as long as the first three GEMMs: they go last, behind the join, so the main stream never waits for it early.
   const bool ov = overlapping(e);
-  if (weight_grad(e, e->at<bf16_t>(e->o_dqkv), 3 * H, 3 * H, e->at<bf16_t>(e->o_x), H, Mtot, 3 * H, H, e->grd(PLB_Q_W), s)) return 1;
+  const bool t8 = e->tn8_call;   // fp8 call: gradient (e5m2) x activation (e4m3) images of all L applications
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dq8), e->at<uint8_t>(e->o_x8), Mtot, 3 * H, H, F8_DQ, F8_X, e->grd(PLB_Q_W), s)
+         : weight_grad(e, e->at<bf16_t>(e->o_dqkv), 3 * H, 3 * H, e->at<bf16_t>(e->o_x), H, Mtot, 3 * H, H, e->grd(PLB_Q_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_Q_W], e->poff[PLB_Q_B], s)) return 1;
-  if (weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_du8), e->at<uint8_t>(e->o_a8), Mtot, I, H, F8_DU, F8_A, e->grd(PLB_FFN_W), s)
+         : weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_FFN_W], e->poff[PLB_FFN_B], s)) return 1;
-  if (weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp8), e->at<uint8_t>(e->o_g8), Mtot, H, I, F8_DP, F8_G, e->grd(PLB_FFNO_W), s)
+         : weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_FFNO_W], e->poff[PLB_FFNO_B], s)) return 1;
-  if (weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp18), e->at<uint8_t>(e->o_c8), Mtot, H, H, F8_DP1, F8_C, e->grd(PLB_DENSE_W), s)
+         : weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
   if (ov) {
     if (s2 != s) HIPTRY(hipStreamWaitEvent(s, e->ev_join, 0));
     if (reduce_piece(e, 0, e->poff[PLB_Q_W], s)) return 1;                    // embeddings, map-in, LN2

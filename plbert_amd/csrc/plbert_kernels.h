@@ -96,8 +96,12 @@ typedef struct {
   int Mtot, N, K;
   int rows_per_split, splits;
   float* slab;
+  const float* deq_a; const float* deq_b;  // fp8 form only (plb_launch_gemm_tn_fp8): 1 / scale of the two 1-byte images
 } PlbGemmTN;
 int plb_launch_gemm_tn(const PlbGemmTN* p, hipStream_t stream);
+// fp8 form of plb_launch_gemm_tn_big (gemm_tn_fp8.hip): A = e5m2 image [rows, Ncols], B = e4m3 image [rows, K], lda / ldb in
+// bytes (multiples of 16); Ncols % 256 == 0, K % 256 == 0, rows_per_split % 128 == 0, Mtot % 128 == 0
+int plb_launch_gemm_tn_fp8(const PlbGemmTN* p, hipStream_t stream);
 // 256x256-tile pipeline version: Ncols % 256 == 0, K % 256 == 0 (gemm_big.hip)
 int plb_launch_gemm_tn_big(const PlbGemmTN* p, hipStream_t stream);
 
@@ -144,7 +148,8 @@ typedef struct {
 // n consecutive sites. |x| maximum of a bf16 / fp32 buffer into a site (atomic max; zero it first),
 // scale update (delayed scaling: scale = fmax / amax, deq = 1 / scale, amax reset), quantisation of a bf16 / fp32 matrix
 int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols, int ld, float* amax, hipStream_t stream);
-int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, hipStream_t stream);
+// group: runs of `group` consecutive sites share one scale (from the largest maximum of the run); 1 = every site its own
+int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, int group, hipStream_t stream);
 int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int cols, int ld, const float* scale, uint8_t* out, int ldo,
                         int bf8, hipStream_t stream);
 int plb_launch_ln_fwd(const PlbLayerNorm* p, hipStream_t stream);

@@ -875,16 +875,24 @@ __global__ __launch_bounds__(256) void amax_kernel(const void* X, size_t rows, i
 // Delayed scaling: the scale a tensor is quantised with in the NEXT step is fmax / (the maximum seen in this one);
 // a site that saw nothing (amax 0) keeps its scale. deq = 1 / scale is what the GEMM epilogues multiply by.
 // One wave per site: maximum over the site's F8_SLOTS words, then the update, then the words are cleared.
-__global__ __launch_bounds__(64) void fp8_scales_kernel(float* amax, float* scale, float* deq, int n, float fmax) {
-  const int i = blockIdx.x, lane = threadIdx.x;
-  if (i >= n) return;
-  float* w = amax + (size_t)i * F8_SLOTS * F8_STRIDE + lane * F8_STRIDE;
-  const float a = wave_max(w[0]);
-  w[0] = 0.f;
-  if (lane == 0 && a > 0.f && a < INFINITY) {
-    scale[i] = fmax / a;
-    deq[i] = a / fmax;
+// group > 1: sites come in runs of `group` entries (the L applications of the shared layer at one operand site) that share
+// ONE scale, formed from the largest maximum of the run — the weight-gradient GEMM sums products of two images over all
+// applications in one launch with one dequantisation factor, so every application's image must be on the same scale.
+__global__ __launch_bounds__(64) void fp8_scales_kernel(float* amax, float* scale, float* deq, int n, float fmax, int group) {
+  const int g0 = blockIdx.x * group, lane = threadIdx.x;
+  if (g0 >= n) return;
+  float a = 0.f;
+  for (int i = g0; i < g0 + group && i < n; ++i) {
+    float* w = amax + (size_t)i * F8_SLOTS * F8_STRIDE + lane * F8_STRIDE;
+    a = fmaxf(a, w[0]);
+    w[0] = 0.f;
   }
+  a = wave_max(a);
+  if (a > 0.f && a < INFINITY)
+    for (int i = g0 + lane; i < g0 + group && i < n; i += 64) {
+      scale[i] = fmax / a;
+      deq[i] = a / fmax;
+    }
 }
 // out[r][c] = fp8(x[r][c] * scale): 8 elements per thread
 template <bool BF16>
@@ -1118,9 +1126,10 @@ extern "C" int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols
   else hipLaunchKernelGGL((amax_kernel<false>), dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld, amax);
   return LAUNCH_OK();
 }
-extern "C" int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, hipStream_t stream) {
+extern "C" int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, int group, hipStream_t stream) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(fp8_scales_kernel, dim3(n), dim3(64), 0, stream, amax, scale, deq, n, fmax);
+  if (group < 1) group = 1;
+  hipLaunchKernelGGL(fp8_scales_kernel, dim3((n + group - 1) / group), dim3(64), 0, stream, amax, scale, deq, n, fmax, group);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int cols, int ld, const float* scale,

@@ -343,3 +343,36 @@ def test_fp8_gelu_stash_forms_forward_then_backward(M, N, K, with16):
     else:
         assert (du == 7.0).all()
         assert rel_l2(colp.sum(0), want.sum(0)) < 2e-2
+
+
+@pytest.mark.parametrize("Mtot,N,K,splits", [(8192, 768, 768, 28), (8192, 2304, 768, 9), (12288, 768, 2048, 10),
+                                            (8192, 256, 256, 1), (16384, 2048, 768, 10), (8192 + 128, 1024, 1024, 16)])
+def test_fp8_weight_gradient_gemm(Mtot, N, K, splits):
+    """dW[N,K] = A^T·B over token rows on 1-byte token-major images (csrc/gemm_tn_fp8.hip: ds_read_b64_tr_b8 fragments,
+    block-scaled fp8 MFMA): e5m2 gradient image x e4m3 activation image, against fp64 on the dequantised operands — the
+    only difference is the accumulation order (fp32 inside the kernel, fixed-order slab reduction)."""
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(Mtot + N + K)
+    A8, Ad, sa = _q2(torch.randn(Mtot, N, device=DEV, generator=g) * 0.01, True)
+    B8, Bd, sb = _q2(torch.randn(Mtot, K, device=DEV, generator=g), False)
+    deq = torch.tensor([1.0 / sa, 1.0 / sb], device=DEV)
+    rps = -(-Mtot // splits)
+    rps = (rps + 127) // 128 * 128
+    splits = -(-Mtot // rps)
+    slab = torch.zeros(splits, N, K, device=DEV)
+    out = torch.zeros(N, K, device=DEV)
+    p = _lib.PlbGemmTN()
+    p.A, p.lda, p.Ncols, p.B, p.ldb = A8.view(torch.uint8).data_ptr(), N, N, B8.view(torch.uint8).data_ptr(), K
+    p.Mtot, p.N, p.K, p.rows_per_split, p.splits, p.slab = Mtot, N, K, rps, splits, slab.data_ptr()
+    p.deq_a, p.deq_b = deq.data_ptr(), deq.data_ptr() + 4
+    assert L.plb_launch_gemm_tn_fp8(C.byref(p), stream()) == 0
+    assert L.plb_launch_reduce_slabs(slab.data_ptr(), splits, N * K, out.data_ptr(), 0, stream()) == 0
+    torch.cuda.synchronize()
+    want = (Ad.double().T @ Bd.double()).float()
+    assert rel_l2(out, want) < 1e-5
+    # and bitwise reproducible
+    out2 = torch.zeros_like(out)
+    assert L.plb_launch_gemm_tn_fp8(C.byref(p), stream()) == 0
+    assert L.plb_launch_reduce_slabs(slab.data_ptr(), splits, N * K, out2.data_ptr(), 0, stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
