@@ -15,7 +15,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # hipcc then selects the AGPR form for EVERY MFMA, so the S / dP tiles that the softmax arithmetic consumes land in
 # accumulator registers and cost a v_accvgpr_read each (+50 % VALU in a loop whose VALU and MFMA time are level). With
 # the VGPR form selected first, the register allocator places each MFMA result where its users want it.
-EXTRA_FLAGS = {"attn_bwd_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# The fp8 translation units: LLVM's MachineSink pass moves the block-scaled fp8 MFMAs (8-register operand tuples) out of
+# their hand-placed slots — whole phases of 16-23 MFMAs ended up back to back in the loop latch, the LDS reads and DMA
+# issues that were dealt into their shadows before them (the bf16 builds keep every MFMA in its slot). With the pass off the
+# K loops are as written and the kernels need 15-30 fewer registers (tools: count v_mfma runs between sched_barriers).
+_NO_SINK = ["-mllvm", "-disable-machine-sink"]
+EXTRA_FLAGS = {"attn_bwd_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               "gemm_fp8.hip": _NO_SINK, "gemm_fp8_ln.hip": _NO_SINK, "gemm_tn_fp8.hip": _NO_SINK}
 
 
 def _hipcc():

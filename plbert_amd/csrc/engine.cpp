@@ -527,8 +527,11 @@ static bool fp8_shapes_ok(const PlbEngine* e, int64_t Tp) {
   if (Tp % 128) return false;
   return (3 * H) % 384 == 0 || (3 * H) % 256 == 0;
 }
-// per-tensor e4m3 copies of the fp8 GEMMs' weights (exact amax: the weights are known)
-static int fp8_quantize_weights(PlbEngine* e, hipStream_t s) {
+// per-tensor e4m3 copies of the fp8 GEMMs' weights.
+// exact = true (after plb_sync_weights / plb_set_fp8: the weights may be anything): maximum, scale, quantisation — three
+//   passes. exact = false (after an AdamW step): ONE launch quantises all copies with the scale the previous
+//   quantisation's maxima give and records the new maxima (a weight moves by <= lr per step; values are clamped).
+static int fp8_quantize_weights(PlbEngine* e, hipStream_t s, bool exact = true) {
   const int H = e->H, I = e->I;
   struct W { int w; const void* src; int bf16; int rows, cols; int64_t dst; } ws[F8W_N] = {
       {F8W_QKV, e->par(PLB_Q_W), 0, 3 * H, H, e->o_wq8},
@@ -539,17 +542,24 @@ static int fp8_quantize_weights(PlbEngine* e, hipStream_t s) {
       {F8W_1T, e->infer ? nullptr : e->at<bf16_t>(e->o_w1T), 1, H, I, e->o_w1T8},
       {F8W_QKVT, e->infer ? nullptr : e->at<bf16_t>(e->o_wqkvT), 1, H, 3 * H, e->o_wqT8},
       {F8W_DT, e->infer ? nullptr : e->at<bf16_t>(e->o_wdT), 1, H, H, e->o_wdT8}};
-  HIPTRY(hipMemsetAsync(f8_amax(e, f8_w(e, 0)), 0, F8W_N * F8_AMAX_WORDS * sizeof(float), s));
-  for (auto& w : ws) {
-    if (!w.src) continue;
-    TRY(plb_launch_amax(w.src, w.bf16, (size_t)w.rows, w.cols, w.cols, f8_amax(e, f8_w(e, w.w)), s));
+  if (exact) {
+    HIPTRY(hipMemsetAsync(f8_amax(e, f8_w(e, 0)), 0, F8W_N * F8_AMAX_WORDS * sizeof(float), s));
+    for (auto& w : ws) {
+      if (!w.src) continue;
+      TRY(plb_launch_amax(w.src, w.bf16, (size_t)w.rows, w.cols, w.cols, f8_amax(e, f8_w(e, w.w)), s));
+    }
   }
+  // amax -> scale (and the maxima are cleared: the quantisation below records this step's)
   TRY(plb_launch_fp8_scales(f8_amax(e, f8_w(e, 0)), f8_scale(e, f8_w(e, 0)), f8_deq(e, f8_w(e, 0)), F8W_N, 448.f, 1, s));
+  const void* src[8]; int bf[8]; size_t n[8]; const float* sc[8]; uint8_t* dst[8]; float* am[8];
+  int k = 0;
   for (auto& w : ws) {
     if (!w.src) continue;
-    TRY(plb_launch_quantize(w.src, w.bf16, (size_t)w.rows, w.cols, w.cols, f8_scale(e, f8_w(e, w.w)), e->at<uint8_t>(w.dst),
-                            w.cols, 0, s));
+    src[k] = w.src; bf[k] = w.bf16; n[k] = (size_t)w.rows * w.cols; sc[k] = f8_scale(e, f8_w(e, w.w));
+    dst[k] = e->at<uint8_t>(w.dst); am[k] = f8_amax(e, f8_w(e, w.w));
+    ++k;
   }
+  TRY(plb_launch_quantize_multi(k, src, bf, n, sc, dst, am, s));
   e->fp8_wstale = false;
   return 0;
 }
@@ -563,7 +573,7 @@ static int fp8_update_scales(PlbEngine* e, hipStream_t s) {
   return 0;
 }
 
-static int sync_transposes(PlbEngine* e, hipStream_t s) {
+static int sync_transposes(PlbEngine* e, hipStream_t s, bool exact_fp8 = true) {
   const int H = e->H, I = e->I, E = e->E;
 
   if (e->NT) {  // bias of the token head padded to NTp columns (fused GEMM + CE passes)
@@ -572,7 +582,7 @@ static int sync_transposes(PlbEngine* e, hipStream_t s) {
   }
   if (e->infer) {  // the transposed copies serve the backward only
     e->tok_pad_zeroed = true;
-    if (e->fp8_on) return fp8_quantize_weights(e, s);
+    if (e->fp8_on) return fp8_quantize_weights(e, s, exact_fp8 || e->fp8_wstale);
     return 0;
   }
   // fused QKV [3H,H] -> [H,3H]; the three tensors are adjacent in the flat buffer
@@ -587,7 +597,7 @@ static int sync_transposes(PlbEngine* e, hipStream_t s) {
     TRY(plb_launch_transpose_cast(e->par(PLB_TOK_W), e->NT, H, e->at<bf16_t>(e->o_wtT), e->NTp, s));
   }
   e->tok_pad_zeroed = true;
-  if (e->fp8_on) return fp8_quantize_weights(e, s);
+  if (e->fp8_on) return fp8_quantize_weights(e, s, exact_fp8 || e->fp8_wstale);
   return 0;
 }
 
@@ -1548,5 +1558,5 @@ extern "C" int plb_adamw_step(PlbEngine* e, double lr, double beta1, double beta
                          (size_t)(e->ptotal - o), lr, beta1, beta2, eps, weight_decay, e->tok_steps, grad_scale,
                          e->at<unsigned int>(e->o_lnerr), 0, s));
   }
-  return sync_transposes(e, s);
+  return sync_transposes(e, s, false);   // fp8 copies: delayed scaling from here on (the weights moved by one AdamW step)
 }

@@ -152,6 +152,10 @@ int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols, int ld, f
 int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, int group, hipStream_t stream);
 int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int cols, int ld, const float* scale, uint8_t* out, int ldo,
                         int bf8, hipStream_t stream);
+// the fp8 copies of up to 8 contiguous weight matrices in one launch: dst[i] = e4m3(src[i] * scale[i][0]); amax[i] (a site)
+// collects max |src[i]| for the next step's scale (delayed scaling)
+int plb_launch_quantize_multi(int n, const void* const* src, const int* is_bf16, const size_t* elements,
+                              const float* const* scale, uint8_t* const* dst, float* const* amax, hipStream_t stream);
 int plb_launch_ln_fwd(const PlbLayerNorm* p, hipStream_t stream);
 int plb_launch_ln_bwd(const PlbLayerNorm* p, hipStream_t stream);
 

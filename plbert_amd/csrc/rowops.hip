@@ -918,6 +918,34 @@ __global__ __launch_bounds__(256) void quantize_kernel(const void* X, size_t row
   }
 }
 
+// The fp8 weight copies of a training step in ONE launch (blockIdx.y = weight): quantise with the scale the previous
+// quantisation's maximum gave (delayed scaling: a weight moves by <= lr per step, the clamp covers the rest) and record this
+// step's maximum for the next. Contiguous matrices (ld == cols).
+struct QuantMulti { const void* src[8]; uint8_t* dst[8]; const float* scale[8]; float* amax[8]; size_t n8[8]; int bf16[8]; };
+__global__ __launch_bounds__(256) void quantize_multi_kernel(QuantMulti q) {
+  const int w = blockIdx.y;
+  const float s = q.scale[w][0];
+  const size_t n = q.n8[w];
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    float f[8];
+    if (q.bf16[w]) {
+      unpack8(*(const uint4*)((const bf16_t*)q.src[w] + i * 8), f);
+    } else {
+      const float4 a = *(const float4*)((const float*)q.src[w] + i * 8), b = *(const float4*)((const float*)q.src[w] + i * 8 + 4);
+      f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+    uint2 o;
+    o.x = pack_fp8x4(f[0] * s, f[1] * s, f[2] * s, f[3] * s, false);
+    o.y = pack_fp8x4(f[4] * s, f[5] * s, f[6] * s, f[7] * s, false);
+    *(uint2*)(q.dst[w] + i * 8) = o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(f[j]));
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) atomic_max_abs(q.amax[w], m, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
 // AlbertModel pooler (modeling_albert.py:403): one wave per output feature, fp32 dot over H, tanh.
 __global__ __launch_bounds__(256) void pooler_kernel(const float* hidden, int S, int H, const float* W, const float* bias,
                                                      float* pooled) {
@@ -1140,6 +1168,21 @@ extern "C" int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int 
   ProfScope ps(PLB_K_FP8, stream, 0, (double)rows * cols * (is_bf16 ? 3 : 5));
   if (is_bf16) hipLaunchKernelGGL((quantize_kernel<true>), dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld, scale, out, ldo, bf8);
   else hipLaunchKernelGGL((quantize_kernel<false>), dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld, scale, out, ldo, bf8);
+  return LAUNCH_OK();
+}
+// n <= 8 contiguous matrices (elements[i] % 8 == 0): dst[i] = e4m3(src[i] * scale[i][0]), amax[i] <- max |src[i]|
+extern "C" int plb_launch_quantize_multi(int n, const void* const* src, const int* is_bf16, const size_t* elements,
+                                         const float* const* scale, uint8_t* const* dst, float* const* amax, hipStream_t stream) {
+  if (n < 1 || n > 8) return 1;
+  QuantMulti q = {};
+  size_t bytes = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!src[i] || !dst[i] || !scale[i] || !amax[i] || elements[i] % 8) return 1;
+    q.src[i] = src[i]; q.dst[i] = dst[i]; q.scale[i] = scale[i]; q.amax[i] = amax[i]; q.n8[i] = elements[i] / 8; q.bf16[i] = is_bf16[i];
+    bytes += elements[i] * (is_bf16[i] ? 3 : 5);
+  }
+  ProfScope ps(PLB_K_FP8, stream, 0, (double)bytes);
+  hipLaunchKernelGGL(quantize_multi_kernel, dim3(128, n), dim3(256), 0, stream, q);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_pooler(const float* hidden, int B, int S, int H, const float* W, const float* bias, float* pooled,

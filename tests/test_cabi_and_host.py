@@ -264,3 +264,35 @@ def test_library_compiles_without_warnings(tmp_path):
         out, _ = p.communicate()
         assert p.returncode == 0, out[-2000:]
         assert "warning" not in out, f"{src}:\n{out[:3000]}"
+
+
+def test_fp8_mfmas_stay_in_their_hand_placed_slots(tmp_path):
+    """The interleaved K loops place ONE MFMA per slot and deal LDS reads / DMA issues into its shadow; sched_barrier pins
+    that order for the machine scheduler, but LLVM's MachineSink pass runs later and — in the fp8 builds only (8-register
+    operand tuples) — sank whole phases of MFMAs into the loop latch (runs of 16-23 back to back, +15-30 VGPRs). build.py
+    compiles the fp8 translation units with that pass off; checked here on the assembly of the weight-gradient kernel:
+    between two sched_barrier markers there is never more than one MFMA."""
+    import subprocess
+
+    from plbert_amd import build as plb_build
+
+    src = os.path.join(ROOT, "plbert_amd", "csrc", "gemm_tn_fp8.hip")
+    out = str(tmp_path / "tn8.s")
+    cmd = [plb_build._hipcc(), *plb_build.FLAGS, *plb_build.EXTRA_FLAGS.get("gemm_tn_fp8.hip", []), "-x", "hip", "-S",
+           "--cuda-device-only", src, "-o", out]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    run = best = total = 0
+    for ln in open(out):
+        t = ln.strip()
+        if not t or t.startswith(";"):
+            if "sched_barrier" in t:
+                run = 0
+            continue
+        if t.startswith("v_mfma"):
+            run += 1
+            total += 1
+            best = max(best, run)
+        else:
+            run = 0
+    assert total == 64 and best == 1, (total, best)   # two K-tiles of 32 MFMAs, each alone in its slot

@@ -369,7 +369,7 @@ def test_fp8_weight_gradient_gemm(Mtot, N, K, splits):
     assert L.plb_launch_reduce_slabs(slab.data_ptr(), splits, N * K, out.data_ptr(), 0, stream()) == 0
     torch.cuda.synchronize()
     want = (Ad.double().T @ Bd.double()).float()
-    assert rel_l2(out, want) < 1e-5
+    assert rel_l2(out, want) < 5e-5                                          # fp32 accumulation over >= 8192 rows
     # and bitwise reproducible
     out2 = torch.zeros_like(out)
     assert L.plb_launch_gemm_tn_fp8(C.byref(p), stream()) == 0
