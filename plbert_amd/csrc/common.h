@@ -56,7 +56,9 @@ DEVI float wave_max(float v) {
 // 0x7f = NaN in e4m3fn, inf in e5m2: tools/probe_fp8.hip), so clamp to the largest finite value first.
 DEVI uint32_t pack_fp8x4(float a, float b, float c, float d, bool bf8) {
   const float mx = bf8 ? 57344.f : 448.f;
-  a = fminf(fmaxf(a, -mx), mx); b = fminf(fmaxf(b, -mx), mx); c = fminf(fmaxf(c, -mx), mx); d = fminf(fmaxf(d, -mx), mx);
+  // one v_med3_f32 per value (fminf(fmaxf()) is two instructions plus canonicalising maxima on MFMA outputs)
+  a = __builtin_amdgcn_fmed3f(a, -mx, mx); b = __builtin_amdgcn_fmed3f(b, -mx, mx);
+  c = __builtin_amdgcn_fmed3f(c, -mx, mx); d = __builtin_amdgcn_fmed3f(d, -mx, mx);
   int v = 0;
   if (bf8) { v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, v, false); v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true); }
   else { v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false); v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true); }
