@@ -1108,7 +1108,7 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
   const bool f8 = f8_call(e, Tp, true);
   const bool calib = e->fp8_on && !f8;
   // ffn.bias gradient from the dU GEMM's epilogue: 2 partial rows per row tile of the kernel that runs it
-  const int du_rows = e->u_is_derivative ? (f8 ? 2 * (int)(Tp / 128) : 2 * (int)(Tp / 256))
+  const int du_rows = e->u_is_derivative ? (f8 ? 2 * (int)(Tp / plb_gemm_nt_fp8_gelud_tile_rows((int)Tp)) : 2 * (int)(Tp / 256))
                                          : (f8 ? 2 * (int)(Tp / 128) : plb_gemm_nt_colpart_rows((int)Tp, I, H));
   bf16_t* da = e->at<bf16_t>(e->o_da);
   bf16_t* dctx = e->at<bf16_t>(e->o_dctx);

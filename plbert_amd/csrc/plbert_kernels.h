@@ -80,6 +80,7 @@ int plb_launch_gemm_nt_fp8(const PlbGemmNT* p, int act, int a_bf8, hipStream_t s
 // bf16 image (C2 / C) may be NULL: only the fp8 image leaves. Same shape rules as the bf16 forms, K % 128 == 0; 3 = no form.
 int plb_launch_gemm_nt_fp8_ln(const PlbGemmNT* p, int mode, int a_bf8, hipStream_t stream);
 int plb_launch_gemm_nt_fp8_gelud(const PlbGemmNT* p, int backward, int a_bf8, hipStream_t stream);
+int plb_gemm_nt_fp8_gelud_tile_rows(int M);  // rows of the tile that launcher uses at this M (colpart: 2 rows per row tile)
 int plb_ln_fault_take(void);  // fault injection state shared by the LayerNorm launchers (plb_debug_ln_fault)
 int plb_launch_gemm_nt(const PlbGemmNT* p, int act, int out_f32, hipStream_t stream);
 int plb_gemm_nt_colpart_rows(int M, int N, int K);  // rows of colpart written for this shape (0: unsupported)

@@ -402,13 +402,15 @@ def test_full_size_properties_config_d():
 def test_full_size_properties_fp8():
     """BASELINE configs[4] at the headline size (768/12, batch 32 x 512) in fp8 mode — since round 4 EVERY projection GEMM
     of the layer (forward, dX and the weight gradients) on e4m3 / e5m2 images: finite, near ln(188), linear over quarter
-    batches and permutation-invariant within the fp8 path's stated tolerances. The comparisons here are between TWO fp8
-    evaluations (each within 0.25 per tensor of the bf16 path, tests/test_gpu_fp8.py), whose delayed scales moreover come
-    from different previous calls (a quarter batch is quantised with the scales the full batch left, and vice versa):
-    measured 0.34 for the whole flat gradient at this size, bound 0.45; e5m2 gradients carry two mantissa bits."""
+    batches and permutation-invariant within the fp8 path's stated tolerances. The comparisons here are between fp8
+    evaluations whose delayed scales come from DIFFERENT previous calls (a quarter batch, whose gradients are 4x the full
+    batch's, is quantised with the scales the full batch left, and vice versa). Measured (tools/fp8_diag.py): every call
+    within 0.10-0.11 of the bf16 path in whole-gradient relative L2 whatever preceded it, a permuted batch within 0.025 of
+    the unpermuted fp8 call. (Round 4 found a real bug with exactly this test: the scales were updated before the
+    weight-gradient GEMMs had dequantised with them — 0.65 on the permuted call after the quarter batches.)"""
     pcfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
                                    max_position_embeddings=512, num_hidden_layers=12)
-    _size_independent_properties(pcfg, 32, 512, fp8=True, tol_lin=0.45, tol_perm=0.45)
+    _size_independent_properties(pcfg, 32, 512, fp8=True, tol_lin=0.25, tol_perm=0.08)
 
 
 def test_layernorm_in_gemm_epilogue_matches_separate_kernels(monkeypatch):
