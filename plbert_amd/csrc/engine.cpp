@@ -1252,84 +1252,66 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   const int T = B * S;
   const int64_t Tp = rup(T, 128);
   const int64_t Mtot = (int64_t)L * Tp;
-  auto side_work = [&]() -> int {
-    PlbGemmNT g;
-    // side stream -------------------------------------------------------------------------------------------------------
-    bf16_t* evec = e->at<bf16_t>(e->o_e);
-    bf16_t* de = e->at<bf16_t>(e->o_de);
-    memset(&g, 0, sizeof(g));
-    g.A = dy; g.lda = H; g.B = e->at<bf16_t>(e->o_winT); g.ldb = H; g.M = (int)Tp; g.N = E; g.K = H; g.Mstore = (int)Tp;
-    g.C = de; g.ldc = E;
-    TRY(plb_launch_gemm_nt(&g, 0, 0, s2));
-    if (weight_grad(e, dy, H, H, evec, E, Tp, H, E, e->grd(PLB_MAP_W), s2, s2 != s)) return 1;
-    TRY(plb_launch_colsum(dy, 1, (size_t)Tp, H, H, e->grd(PLB_MAP_B), H, 0, scratch2, 128, s2));
-    HIPTRY(hipMemsetAsync(e->grd(PLB_TYPE_EMB), 0, (size_t)e->psize[PLB_TYPE_EMB] * 4, s2));
-    PlbEmbed em;
-    memset(&em, 0, sizeof(em));
-    em.ids = masked_ids; em.T = T; em.S = S; em.E = E; em.V = e->V;
-    em.word = e->par(PLB_WORD_EMB); em.pos = e->par(PLB_POS_EMB); em.type0 = e->par(PLB_TYPE_EMB);
-    em.gamma = e->par(PLB_EMB_LN_W); em.beta = e->par(PLB_EMB_LN_B); em.eps = e->c.layer_norm_eps;
-    em.dout = de; em.lddo = E; em.dword = e->grd(PLB_WORD_EMB); em.dpos = e->grd(PLB_POS_EMB);
-    em.dx = e->at<float>(e->o_dxe);
-    em.partials = e->at<float>(e->o_parte); em.nblocks = e->emb_blocks;
-    TRY(plb_launch_embed_bwd(&em, s2));
-    TRY(plb_launch_embed_scatter(&em, e->P, s2));
-    TRY(plb_launch_colsum(em.partials, 0, (size_t)e->emb_blocks, 2 * E, 2 * E, e->grd(PLB_EMB_LN_W), 2 * E, 0, scratch2, 1, s2));
-    // token_type row 0 receives every token's gradient = the column sums of dpos
-    TRY(plb_launch_colsum(e->grd(PLB_POS_EMB), 0, (size_t)e->P, E, E, e->grd(PLB_TYPE_EMB), E, 0, scratch2, 1, s2));
-    // Q/K/V biases: the attention-backward kernels left the column sums of every 32-row patch they stored, per application
-    // ([L][B*QT*4][3H])
-    TRY(plb_launch_colsum(e->at<float>(e->o_qkvcol), 0, (size_t)L * (size_t)(B * ((S + 127) / 128) * 4), 3 * H, 3 * H, e->grd(PLB_Q_B),
-                          3 * H, 0, scratch2, 16, s2));
-    if (du_rows > 0)
-      TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 16, s2));
-    else
-      TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 64, s2));
-    // LayerNorm-backward partials [L*blocks][3H]: dgamma | dbeta | column sums of dx. (Summing the L applications into
-    // one image inside the kernel — PlbLayerNorm.accumulate — was measured: the read-modify-write costs the main stream
-    // 2.5 us per launch to save side-stream traffic that is hidden behind the weight-gradient GEMMs anyway.) The third block is the bias
-    // gradient of the Linear that produced the LayerNorm's input (dense.bias = colsum(dpre1), ffn_output.bias =
-    // colsum(dpre2)): no pass over the stacked gradients.
-    const size_t prow = (size_t)L * e->part_rows_used;
-    TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch2, 64, s2));
-    TRY(plb_launch_copy_cols(scratch2, 64, 3 * H, 2 * H, H, e->grd(PLB_DENSE_B), s2));
-    TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch2, 64, s2));
-    TRY(plb_launch_copy_cols(scratch2, 64, 3 * H, 2 * H, H, e->grd(PLB_FFNO_B), s2));
-    if (s2 != s) HIPTRY(hipEventRecord(e->ev_join, s2));
-    return 0;
-  };
+  PlbGemmNT g;
+  // side stream -------------------------------------------------------------------------------------------------------
+  bf16_t* evec = e->at<bf16_t>(e->o_e);
+  bf16_t* de = e->at<bf16_t>(e->o_de);
+  memset(&g, 0, sizeof(g));
+  g.A = dy; g.lda = H; g.B = e->at<bf16_t>(e->o_winT); g.ldb = H; g.M = (int)Tp; g.N = E; g.K = H; g.Mstore = (int)Tp;
+  g.C = de; g.ldc = E;
+  TRY(plb_launch_gemm_nt(&g, 0, 0, s2));
+  if (weight_grad(e, dy, H, H, evec, E, Tp, H, E, e->grd(PLB_MAP_W), s2, s2 != s)) return 1;
+  TRY(plb_launch_colsum(dy, 1, (size_t)Tp, H, H, e->grd(PLB_MAP_B), H, 0, scratch2, 128, s2));
+  HIPTRY(hipMemsetAsync(e->grd(PLB_TYPE_EMB), 0, (size_t)e->psize[PLB_TYPE_EMB] * 4, s2));
+  PlbEmbed em;
+  memset(&em, 0, sizeof(em));
+  em.ids = masked_ids; em.T = T; em.S = S; em.E = E; em.V = e->V;
+  em.word = e->par(PLB_WORD_EMB); em.pos = e->par(PLB_POS_EMB); em.type0 = e->par(PLB_TYPE_EMB);
+  em.gamma = e->par(PLB_EMB_LN_W); em.beta = e->par(PLB_EMB_LN_B); em.eps = e->c.layer_norm_eps;
+  em.dout = de; em.lddo = E; em.dword = e->grd(PLB_WORD_EMB); em.dpos = e->grd(PLB_POS_EMB);
+  em.dx = e->at<float>(e->o_dxe);
+  em.partials = e->at<float>(e->o_parte); em.nblocks = e->emb_blocks;
+  TRY(plb_launch_embed_bwd(&em, s2));
+  TRY(plb_launch_embed_scatter(&em, e->P, s2));
+  TRY(plb_launch_colsum(em.partials, 0, (size_t)e->emb_blocks, 2 * E, 2 * E, e->grd(PLB_EMB_LN_W), 2 * E, 0, scratch2, 1, s2));
+  // token_type row 0 receives every token's gradient = the column sums of dpos
+  TRY(plb_launch_colsum(e->grd(PLB_POS_EMB), 0, (size_t)e->P, E, E, e->grd(PLB_TYPE_EMB), E, 0, scratch2, 1, s2));
+  // Q/K/V biases: the attention-backward kernels left the column sums of every 32-row patch they stored, per application
+  // ([L][B*QT*4][3H])
+  TRY(plb_launch_colsum(e->at<float>(e->o_qkvcol), 0, (size_t)L * (size_t)(B * ((S + 127) / 128) * 4), 3 * H, 3 * H, e->grd(PLB_Q_B),
+                        3 * H, 0, scratch2, 16, s2));
+  if (du_rows > 0)
+    TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 16, s2));
+  else
+    TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 64, s2));
+  // LayerNorm-backward partials [L*blocks][3H]: dgamma | dbeta | column sums of dx. (Summing the L applications into
+  // one image inside the kernel — PlbLayerNorm.accumulate — was measured: the read-modify-write costs the main stream
+  // 2.5 us per launch to save side-stream traffic that is hidden behind the weight-gradient GEMMs anyway.) The third block is the bias
+  // gradient of the Linear that produced the LayerNorm's input (dense.bias = colsum(dpre1), ffn_output.bias =
+  // colsum(dpre2)): no pass over the stacked gradients.
+  const size_t prow = (size_t)L * e->part_rows_used;
+  TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch2, 64, s2));
+  TRY(plb_launch_copy_cols(scratch2, 64, 3 * H, 2 * H, H, e->grd(PLB_DENSE_B), s2));
+  TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch2, 64, s2));
+  TRY(plb_launch_copy_cols(scratch2, 64, 3 * H, 2 * H, H, e->grd(PLB_FFNO_B), s2));
+  if (s2 != s) HIPTRY(hipEventRecord(e->ev_join, s2));
   // main stream: shared-layer weight gradients, one token-major GEMM per weight over all L applications ------------
   // Overlapped exchange: a weight's range travels as soon as its GEMM (+ slab reduction) has written it. The small
   // tensors between the weights in the flat order (biases, LayerNorm, embeddings) come from the side stream, which needs
   // about as long as the first three GEMMs: they go last, behind the join, so the main stream never waits for it early.
   const bool ov = overlapping(e);
-  auto main_work = [&]() -> int {
-    const bool t8 = e->tn8_call;   // fp8 call: gradient (e5m2) x activation (e4m3) images of all L applications
-    if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dq8), e->at<uint8_t>(e->o_x8), Mtot, 3 * H, H, F8_DQ, F8_X, e->grd(PLB_Q_W), s)
-           : weight_grad(e, e->at<bf16_t>(e->o_dqkv), 3 * H, 3 * H, e->at<bf16_t>(e->o_x), H, Mtot, 3 * H, H, e->grd(PLB_Q_W), s)) return 1;
-    if (ov && reduce_piece(e, e->poff[PLB_Q_W], e->poff[PLB_Q_B], s)) return 1;
-    if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_du8), e->at<uint8_t>(e->o_a8), Mtot, I, H, F8_DU, F8_A, e->grd(PLB_FFN_W), s)
-           : weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
-    if (ov && reduce_piece(e, e->poff[PLB_FFN_W], e->poff[PLB_FFN_B], s)) return 1;
-    if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp8), e->at<uint8_t>(e->o_g8), Mtot, H, I, F8_DP, F8_G, e->grd(PLB_FFNO_W), s)
-           : weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
-    if (ov && reduce_piece(e, e->poff[PLB_FFNO_W], e->poff[PLB_FFNO_B], s)) return 1;
-    if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp18), e->at<uint8_t>(e->o_c8), Mtot, H, H, F8_DP1, F8_C, e->grd(PLB_DENSE_W), s)
-           : weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
-    return 0;
-  };
-  // Host order of the two enqueues. The hardware starts what it is handed first: with the side stream's ~20 small launches
-  // enqueued ahead of it, the first weight-gradient GEMM (a whole-chip grid) only started once the side stream's first
-  // eight kernels had run — a 130-160 us hole on the main stream in every step (tools/timeline.py on a kernel trace, bf16
-  // and fp8 alike). Main first: the big grid is dispatched at once and the small kernels run beside it.
-  static const bool main_first = [] { const char* v = getenv("PLBERT_TAIL_ORDER"); return !(v && !strcmp(v, "side")); }();
-  if (main_first && s2 != s) {
-    if (main_work()) return 1;
-    if (side_work()) return 1;
-  } else {
-    if (side_work()) return 1;
-    if (main_work()) return 1;
-  }
+  const bool t8 = e->tn8_call;   // fp8 call: gradient (e5m2) x activation (e4m3) images of all L applications
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dq8), e->at<uint8_t>(e->o_x8), Mtot, 3 * H, H, F8_DQ, F8_X, e->grd(PLB_Q_W), s)
+         : weight_grad(e, e->at<bf16_t>(e->o_dqkv), 3 * H, 3 * H, e->at<bf16_t>(e->o_x), H, Mtot, 3 * H, H, e->grd(PLB_Q_W), s)) return 1;
+  if (ov && reduce_piece(e, e->poff[PLB_Q_W], e->poff[PLB_Q_B], s)) return 1;
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_du8), e->at<uint8_t>(e->o_a8), Mtot, I, H, F8_DU, F8_A, e->grd(PLB_FFN_W), s)
+         : weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
+  if (ov && reduce_piece(e, e->poff[PLB_FFN_W], e->poff[PLB_FFN_B], s)) return 1;
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp8), e->at<uint8_t>(e->o_g8), Mtot, H, I, F8_DP, F8_G, e->grd(PLB_FFNO_W), s)
+         : weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
+  if (ov && reduce_piece(e, e->poff[PLB_FFNO_W], e->poff[PLB_FFNO_B], s)) return 1;
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp18), e->at<uint8_t>(e->o_c8), Mtot, H, H, F8_DP1, F8_C, e->grd(PLB_DENSE_W), s)
+         : weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
   if (ov) {
     if (s2 != s) HIPTRY(hipStreamWaitEvent(s, e->ev_join, 0));
     if (reduce_piece(e, 0, e->poff[PLB_Q_W], s)) return 1;                    // embeddings, map-in, LN2
