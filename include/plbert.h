@@ -152,13 +152,18 @@ int plb_loss_fwd_bwd_dual(PlbEngine* e, const int64_t* masked_ids, const int64_t
 int plb_adamw_step(PlbEngine* e, double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step,
                    double grad_scale, void* stream);
 
-/* fp8 mode (BASELINE.json configs[4]): the QKV and the two FFN GEMMs of the forward, and the two FFN dX GEMMs of the
- * backward, run on OCP fp8 operands with fp32 accumulation — e4m3 weights and activations, e5m2 gradients — through the
- * block-scaled MFMA with unit block scales (twice the bf16 MFMA rate); attention, the dense projection, every weight
- * gradient, LayerNorm, the loss and the optimizer stay bf16 / fp32. Per-tensor delayed scaling: a tensor is quantised
- * with 448 (57344) / the maximum it showed in the previous call; the first call after switching the mode on runs in
- * bf16 and only records the maxima. hidden_size 768 or 1024; calls whose GEMM shapes have no pipeline-tile form run
- * in bf16. The reference has no fp8 path: parity is against this library's own bf16 path (tests/test_gpu_fp8.py). */
+/* fp8 mode (BASELINE.json configs[4]): EVERY projection GEMM of the shared layer runs on OCP fp8 operands with fp32
+ * accumulation through the block-scaled MFMA with unit block scales (twice the bf16 MFMA rate) — forward: QKV, dense
+ * (+ LayerNorm 1), FFN up (+ gelu_new), FFN output (+ LayerNorm 2); backward: the four dX GEMMs (two of them carrying a
+ * LayerNorm backward, one the gelu backward) and the four weight-gradient GEMMs over all applications. e4m3 weights and
+ * activations, e5m2 gradients. The 1-byte images are written by the launches that produce the tensors (fused epilogues,
+ * attention kernels), one per application of the layer; attention itself, the head, LayerNorm / softmax statistics, the
+ * loss and the optimizer stay bf16 / fp32. Delayed scaling, one scale per operand SITE shared by the L applications: a
+ * tensor is quantised with 448 / the maximum its site showed in the previous call (gradients: 28672 / the maximum, one
+ * binade of headroom); the first call after switching the mode on — and a training call whose gradient sites have not
+ * been seen yet — runs in bf16 and only records the maxima. hidden_size 768 or 1024; calls whose GEMM shapes have no
+ * pipeline-tile form run in bf16. The reference has no fp8 path (configs/config.yml:15: fp16 autocast): parity is against
+ * this library's own bf16 path (tests/test_gpu_fp8.py: loss within 2e-2, whole-gradient relative L2 0.11). */
 int plb_set_fp8(PlbEngine* e, int32_t on, void* stream);
 int plb_fp8_state(const PlbEngine* e, int32_t* enabled, int32_t* calibrated);
 

@@ -7,7 +7,8 @@ mkdir -p $O
 timeout -k 10 600 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 bash tools/profile_round.sh $tag > $O/profile.log 2>&1; echo "profile rc=$?"
-run() { name=$1; shift; timeout -k 10 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-traffic "$@" > $O/$name.json 2> $O/$name.err; echo "$name rc=$?"; python - "$O/$name.json" <<'PY'
+bash tools/profile_round.sh ${tag}_fp8 --dtype fp8 --no-cpu-baseline --no-secondary > $O/profile_fp8.log 2>&1; echo "profile fp8 rc=$?"
+run() { name=$1; shift; timeout -k 10 400 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-traffic --no-secondary "$@" > $O/$name.json 2> $O/$name.err; echo "$name rc=$?"; python - "$O/$name.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
 print("   ", d["ms_per_step"], "ms", d["value"], "tok/s", "frac", d["step_mfma_frac_wall"], "loss", d["step_loss"], "staged", (d.get("staged") or {}).get("ms_per_step"), "comm", {k: v for k, v in d["comm"].items() if k != "calibration_ms_per_step"})
