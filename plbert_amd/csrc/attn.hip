@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
     delta = d + __shfl_xor(d, 32, 64);
   }
   const size_t stat = ((size_t)b * p.NH + hd) * S + qr;
-  if (h == 0 && q0 + lq < S) p.delta[stat] = delta;
+  if (h == 0 && q0 + lq < S) p.delta[stat] = -delta;   // stored NEGATED: the dK/dV kernel starts its dP accumulators there
   const float lse2 = p.lse[stat] * (p.scale * LOG2E);  // stored as -LSE in raw-score units (PlbAttn.lse)
   const float sl2 = p.scale * LOG2E;
 
@@ -410,8 +410,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   // One tile out of stage CUR (a literal: every LDS address is a lane constant + an immediate). The tile body exists
   // twice more: tiles that cross the length (of keys or of queries) mask, all the others run without a single compare /
   // select — written as one select on a wave-uniform flag, hipcc if-converted the mask into every tile.
-  // Row constants as initial accumulators: dP starts at -delta[q] (q runs over the registers here), so the MFMA chain
-  // leaves dP - delta. Per 32-query block: statistics and the 8 row fragments are read, 8 MFMAs (S, dP), then the 8
+  // Row constants as initial accumulators: dP starts at -delta[q] (q runs over the registers here; the dQ kernel stores
+  // delta negated, so the statistics go into the accumulators as they are), so the MFMA chain leaves dP - delta. Per 32-query block: statistics and the 8 row fragments are read, 8 MFMAs (S, dP), then the 8
   // transposed fragments of the second products are requested BEFORE the softmax arithmetic so they land under it.
 #define DKV_BLOCK(CUR, MASK, qb)                                                                                \
   {                                                                                                             \
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
       const float4 l4 = *(const float4*)&sstat[CUR][0][ql];                                                     \
       const float4 d4 = *(const float4*)&sstat[CUR][1][ql];                                                     \
       s[4 * rg + 0] = l4.x; s[4 * rg + 1] = l4.y; s[4 * rg + 2] = l4.z; s[4 * rg + 3] = l4.w;                   \
-      dp[4 * rg + 0] = -d4.x; dp[4 * rg + 1] = -d4.y; dp[4 * rg + 2] = -d4.z; dp[4 * rg + 3] = -d4.w;           \
+      dp[4 * rg + 0] = d4.x; dp[4 * rg + 1] = d4.y; dp[4 * rg + 2] = d4.z; dp[4 * rg + 3] = d4.w;               \
     }                                                                                                           \
     bf16x8 fq[4], fd[4];                                                                                        \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                          \

@@ -182,7 +182,7 @@ typedef struct {
   float* lse;                   // [B,NH,S] MINUS the log-sum-exp of the scaled scores, in units of RAW scores (-lse/scale): the backward starts its S accumulators there
   // backward
   const bf16_t* dctx; int lddctx;
-  float* delta;                 // [B,NH,S]
+  float* delta;                 // [B,NH,S] scratch between the two backward kernels: MINUS rowsum(dO∘O)
   bf16_t* dqkv; int lddqkv;     // [T,3H]
   float* colpart;               // backward, optional: [B * ceil(S/128) * 4][3H] column sums of dqkv per (sample, 128-row tile, wave)
   int colpart_accumulate;       // add to colpart instead of overwriting (sum over the applications of the shared layer)

@@ -376,3 +376,32 @@ def test_fp8_weight_gradient_gemm(Mtot, N, K, splits):
     assert L.plb_launch_reduce_slabs(slab.data_ptr(), splits, N * K, out2.data_ptr(), 0, stream()) == 0
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
+
+
+def test_fp8_forward_on_an_inference_engine():
+    """plb_forward / plb_loss_fwd in fp8 mode on an engine built without training buffers (one layer of activations, one
+    set of 1-byte images, no transposed weight copies): the calibration call equals the bf16 engine bit for bit, the fp8
+    calls stay close to it and agree with each other."""
+    g = load_golden("real_s128_b8")
+    ocfg, pcfg, sd = golden_cfg(g)
+    B, S = g["labels"].shape
+    lens = g["lengths"].astype(np.int32)
+    ref = HipEngine(pcfg, 188, 0, max_batch=B, max_seq=S, train=False)
+    ref.load_state_dict(sd)
+    _, ph_ref, _ = ref.forward(g["masked"], lens)
+    eng = HipEngine(pcfg, 188, 0, max_batch=B, max_seq=S, train=False)
+    eng.load_state_dict(sd)
+    eng.set_fp8(True)
+    _, ph_cal, _ = eng.forward(g["masked"], lens)
+    assert torch.equal(ph_cal, ph_ref)
+    _, ph8, _ = eng.forward(g["masked"], lens)
+    _, ph8b, _ = eng.forward(g["masked"], lens)
+    torch.cuda.synchronize()
+    v = torch.from_numpy(np.arange(S)[None, :] < lens[:, None]).to(ph8.device)
+    assert not torch.equal(ph8, ph_ref)                                       # the fp8 GEMMs really ran
+    assert rel_l2(ph8[v], ph_ref[v]) < 5e-2 and float((ph8[v] - ph_ref[v]).abs().max()) < 0.25
+    assert rel_l2(ph8b[v], ph8[v]) < 1e-2                                     # delayed scales moved a little between the calls
+    assert np.abs(ph8[v].cpu().numpy() - g["probe_logits"].mean()).max() < 50  # finite, sane
+    off, flat = plbert_amd.masked_indices_to_csr([list(map(int, x)) for x in g["index"]])
+    l8 = float(eng.loss_fwd(g["masked"], g["labels"], lens, off, flat, int(off[-1])).item())
+    assert abs(l8 - float(g["loss"])) / float(g["loss"]) < 2e-2
