@@ -122,10 +122,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224))) void gem
       for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int d = 0; d < 2; ++d) acc[a][b][c][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+// TN_DBG (timing builds only, tools/tn_wait.py): 1 = print, from one workgroup, the share of the K loop a wave spends in the
+// vmcnt wait that precedes phase 4 (is the loop waiting for memory?) and the loop's time per K-tile
+#ifndef TN_DBG
+#define TN_DBG 0
+#endif
+#if TN_DBG
+  unsigned long long tnw_ = 0, tnq_ = 0;
+#define TN_W0() tnq_ = __builtin_readcyclecounter()
+#define TN_W1() tnw_ += __builtin_readcyclecounter() - tnq_
+#else
+#define TN_W0()
+#define TN_W1()
+#endif
 #define LANDED(more)                                                      \
   do {                                                                    \
+    TN_W0();                                                              \
     if (more) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 \
+    TN_W1();                                                              \
   } while (0)
 
   // ---- interleaved K loop (the NT kernel's default form, see gemm_nt_pipeline.h): a phase is {BARRIER, 16 MFMAs}; the
@@ -239,6 +254,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224))) void gem
     LANDED(nk > 1);
   }
   BARRIER();
+#if TN_DBG
+  tnw_ = 0;
+  const unsigned long long tn_c0 = __builtin_readcyclecounter(), tn_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   if (nk > 0) {
     RA4(0, 0, 0); RA4(0, 0, 1); RA4(0, 0, 2); RB4(0, 0, 0, 0); RB4(0, 0, 0, 1);
     int t = 0;
@@ -250,6 +269,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(224))) void gem
     }
     BARRIER();
   }
+#if TN_DBG
+  if ((blockIdx.x == 17 || blockIdx.x == 130) && lane == 0 && (uw == 0 || uw == 5)) {
+    const unsigned long long dc = __builtin_readcyclecounter() - tn_c0, dr = __builtin_amdgcn_s_memrealtime() - tn_r0;
+    printf("TN blk %d wave %d: %d K-tiles, %.3f us per K-tile, %.0f MHz, vmcnt wait %.1f %% of the loop\n", (int)blockIdx.x, uw, nk,
+           (double)dr / 100.0 / nk, (double)dc / ((double)dr / 100.0), 100.0 * (double)tnw_ / (double)dc);
+  }
+#endif
 #undef TN_STEP
 #undef TWO
 #undef NOP_
