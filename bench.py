@@ -226,8 +226,9 @@ def secondary_lines():
                         "workload": j["config"]["workload"], "dominant_kernel": rl.get("kernel"),
                         "dominant_frac": rl.get("frac"), "dominant_peak_TFLOPs": rl.get("peak")}
             if key == "fp8":
-                out[key]["parity"] = ("loss within 2e-2 relative of this build's bf16 path and of the reference; per-tensor "
-                                      "gradient relative L2 <= 0.25 (tests/test_gpu_fp8.py) - NOT the 1e-3 of the bf16 path")
+                out[key]["parity"] = ("loss within 2e-2 relative of this build's bf16 path and of the reference; whole-gradient "
+                                      "relative L2 0.10-0.11, per tensor <= 0.25 (tests/test_gpu_fp8.py, tools/fp8_diag.py) - NOT "
+                                      "the 1e-3 of the bf16 path; no fp8 reference exists")
         except Exception as ex:  # the headline line must still be printed
             out[key] = {"error": repr(ex)}
     return out
@@ -624,7 +625,8 @@ def main():
         if secondary is not None:
             out["secondary"] = secondary
         if args.dtype == "fp8":
-            out["config"]["parity"] = "fp8 path: loss within 2e-2 relative of the bf16 path (tests/test_gpu_fp8.py), not 1e-3"
+            out["config"]["parity"] = ("fp8 path: loss within 2e-2 relative and whole-gradient relative L2 0.10-0.11 of the bf16 "
+                                       "path (tests/test_gpu_fp8.py, tools/fp8_diag.py), not 1e-3")
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Per-kernel SQ counters of the bench step (separate rocprofv3 --pmc passes, kernel trace only beside them), summed per
 # kernel name into gpurun_out/sq_<tag>.csv: MFMA-pipe busy cycles, VALU issue, LDS bank conflicts against busy cycles.
-tag=$1
+tag=$1; shift
 R=$PWD
 O=$R/gpurun_out/sq_$tag
 mkdir -p $O
 export TMPDIR=/tmp
-B="--steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-traffic --no-staged --no-secondary"
+B="--steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-traffic --no-staged --no-secondary $*"
 i=0
-for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES"; do
+for set in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
   i=$((i+1))
   cd /tmp && timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $O/p$i -o t -- python3 $R/bench.py $B > $O/p$i.log 2>&1; echo "pass $i ($set) rc=$?"
 done
