@@ -407,3 +407,37 @@ def test_fp8_forward_on_an_inference_engine():
     off, flat = plbert_amd.masked_indices_to_csr([list(map(int, x)) for x in g["index"]])
     l8 = float(eng.loss_fwd(g["masked"], g["labels"], lens, off, flat, int(off[-1])).item())
     assert abs(l8 - float(g["loss"])) / float(g["loss"]) < 2e-2
+
+
+@pytest.mark.parametrize("B,S,lens", [(3, 512, [512, 512, 512]), (5, 200, [200, 180, 77, 200, 13])])
+def test_fp8_step_on_shapes_without_fused_layernorm_forms(B, S, lens):
+    """Token counts that are no multiple of 1024 take the unfused path (GEMM + LayerNorm kernel, which then writes the
+    1-byte images), ragged rows included; 3 x 512: weight gradients on the images (12 x 1536 rows), 5 x 200 (1024 padded
+    rows -> fused again, but ragged and below the weight-gradient GEMM's row minimum on a 4-layer model): bf16 operands."""
+    layers = 12 if B == 3 else 4
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                                  max_position_embeddings=512, num_hidden_layers=layers)
+    labels, masked, _, idx = plbert_amd.synthetic_batch(B, S, seed=17)
+    idx = [[i for i in ix if i < n] or [0] for ix, n in zip(idx, lens)]
+    for b, n in enumerate(lens):
+        labels[b, n:] = 0
+        masked[b, n:] = 0
+    sd = plbert_amd.deterministic_state_dict(cfg, 188, seed=9)
+    off, flat = plbert_amd.masked_indices_to_csr(idx)
+    args = (masked, labels, np.asarray(lens, np.int32), off, flat, int(off[-1]))
+    ref = HipEngine(cfg, 188, 0, max_batch=B, max_seq=S)
+    ref.load_state_dict(sd)
+    l_ref = float(ref.loss_fwd_bwd(*args).item())
+    eng = HipEngine(cfg, 188, 0, max_batch=B, max_seq=S)
+    eng.load_state_dict(sd)
+    eng.set_fp8(True)
+    assert float(eng.loss_fwd_bwd(*args).item()) == l_ref and torch.equal(eng.grads, ref.grads)   # calibration call
+    l8 = float(eng.loss_fwd_bwd(*args).item())
+    l8b = float(eng.loss_fwd_bwd(*args).item())
+    torch.cuda.synchronize()
+    n = eng.trainable
+    r = rel_l2(eng.grads[:n], ref.grads[:n])
+    assert l8 != l_ref and abs(l8 - l_ref) / l_ref < 2e-2 and abs(l8b - l_ref) / l_ref < 2e-2, (l8, l8b, l_ref)
+    assert r < 0.2, r
+    assert bool(torch.isfinite(eng.grads[:n]).all())
+    assert eng.status()["ln_exchange_timeouts"] == 0
