@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
   const Out8 o8 = {p.dqkv8 ? p.dqkv8 + (tok0 + q0) * p.lddqkv8 + hd * 64 : nullptr, p.lddqkv8, p.dqkv8 ? p.dqkv_scale[0] : 1.0f, true};
   float amax8 = 0.f;
   if (rows_valid > 0)
-    store_transposed<(ATTN_OUT_NT & 2) != 0>(dq0, dq1, p.scale, patch, p.dqkv ? p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64 : nullptr, p.lddqkv,
+    store_transposed<(ATTN_OUT_NT & 2) != 0, true>(dq0, dq1, p.scale, patch, p.dqkv ? p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64 : nullptr, p.lddqkv,
                      rows_valid, lane, cp, p.colpart_accumulate != 0, &o8, &amax8);
   else if (cp && !p.colpart_accumulate) cp[lane] = 0.f;
   if (p.dqkv8 && p.dqkv_amax) {
@@ -493,10 +493,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
     const float qs8 = p.dqkv8 ? p.dqkv_scale[0] : 1.0f;
     const Out8 ok8 = {out8 ? out8 + H : nullptr, p.lddqkv8, qs8, true}, ov8 = {out8 ? out8 + 2 * H : nullptr, p.lddqkv8, qs8, true};
     const bool accq = p.colpart_accumulate != 0;
-    store_transposed<(ATTN_OUT_NT & 4) != 0>(dk0, dk1, p.scale, patch, out ? out + H : nullptr, p.lddqkv, rows_valid, lane_e,
+    store_transposed<(ATTN_OUT_NT & 4) != 0, true>(dk0, dk1, p.scale, patch, out ? out + H : nullptr, p.lddqkv, rows_valid, lane_e,
                                              cp ? cp + H : nullptr, accq, &ok8, &amax8);
     __builtin_amdgcn_wave_barrier();
-    store_transposed<(ATTN_OUT_NT & 4) != 0>(dv0, dv1, 1.0f, patch, out ? out + 2 * H : nullptr, p.lddqkv, rows_valid, lane_e,
+    store_transposed<(ATTN_OUT_NT & 4) != 0, true>(dv0, dv1, 1.0f, patch, out ? out + 2 * H : nullptr, p.lddqkv, rows_valid, lane_e,
                                              cp ? cp + 2 * H : nullptr, accq, &ov8, &amax8);
   } else if (cp && !p.colpart_accumulate) {
     cp[H + lane_e] = 0.f;

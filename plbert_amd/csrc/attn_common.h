@@ -112,8 +112,10 @@ DEVI f32x16 zero16() {
 #endif
 // Optional fp8 copy of the rows a wave stores (fp8 mode): the values AS ROUNDED TO bf16 times qs, saturated, e4m3 or e5m2;
 // amax = running max |value| of the lane (the caller reduces it and reports it to the site). g8 == nullptr: off.
+// BF8: the image's format is fixed by the kernel (forward: e4m3 context, backward: e5m2 gradients) — a compile-time choice,
+// so that only one conversion instruction per pair is emitted.
 struct Out8 { uint8_t* g8; int ld8; float qs; bool bf8; };
-template <bool NT = false>
+template <bool NT = false, bool BF8 = false>
 DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_t* patch, bf16_t* gout, int ldo,
                            int rows_valid, int lane, float* colsum = nullptr, bool accumulate = false,
                            const Out8* o8 = nullptr, float* amax = nullptr) {
@@ -147,8 +149,8 @@ DEVI void store_transposed(const f32x16& a0, const f32x16& a1, float mult, bf16_
         const float f4 = bf_lo(v.z), f5 = bf_hi(v.z), f6 = bf_lo(v.w), f7 = bf_hi(v.w);
         const float q = o8->qs;
         uint2 w;
-        w.x = pack_fp8x4(f0 * q, f1 * q, f2 * q, f3 * q, o8->bf8);
-        w.y = pack_fp8x4(f4 * q, f5 * q, f6 * q, f7 * q, o8->bf8);
+        w.x = pack_fp8x4(f0 * q, f1 * q, f2 * q, f3 * q, BF8);
+        w.y = pack_fp8x4(f4 * q, f5 * q, f6 * q, f7 * q, BF8);
         *(uint2*)(o8->g8 + (size_t)row * o8->ld8 + c * 8) = w;
         *amax = fmaxf(*amax, fmaxf(fmaxf(fmaxf(fabsf(f0), fabsf(f1)), fmaxf(fabsf(f2), fabsf(f3))),
                                    fmaxf(fmaxf(fabsf(f4), fabsf(f5)), fmaxf(fabsf(f6), fabsf(f7)))));

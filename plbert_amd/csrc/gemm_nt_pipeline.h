@@ -923,23 +923,21 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
       bf16_t* const obase = (ACT == 5 ? p.C2 + (size_t)(bm * TM) * p.ldc2 : p.C + (size_t)(bm * TM) * p.ldc) + bn * TN;
       const int ldo = ACT == 5 ? p.ldc2 : p.ldc;
       const int rows_ok = p.Mstore - bm * TM;
+      // fp8 builds with an image requested: every 16-byte chunk of the bf16 image leaves twice — as it is, and as the 8
+      // bytes of the 1-byte image (e4m3 for the forward form's LayerNorm output, e5m2 for the backward form's gradient)
+      const bool img8 = FP8 && p.C8 != nullptr;
+      const float qs8 = img8 ? p.q_scale[0] : 1.0f;
+      constexpr bool bf8o = ACT == 6;
+      float amax8 = 0.f;
+      unsigned char* const qbase = img8 ? p.C8 + (size_t)(bm * TM) * p.ldc8 + bn * TN : nullptr;
 #pragma unroll 4
       for (int c = tid; c < TM * CPR; c += 512) {
         const int r = c / CPR, cc = c - r * CPR;
         const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
-        if (r < rows_ok) OUT_STORE((obase + (size_t)r * ldo + cc * 8), v);
-      }
-      if constexpr (FP8) {
-        if (p.C8) {   // the same rows once more, as bytes: 8 values of the bf16 image -> 8 bytes per lane
-          const float qs8 = p.q_scale[0];
-          const bool bf8o = p.c8_bf8 != 0;
-          float amax8 = 0.f;
-          unsigned char* const qbase = p.C8 + (size_t)(bm * TM) * p.ldc8 + bn * TN;
-#pragma unroll 4
-          for (int c = tid; c < TM * CPR; c += 512) {
-            const int r = c / CPR, cc = c - r * CPR;
-            const uint4 v = *(const uint4*)&smem[r * OROW + cc * 8];
-            if (r < rows_ok) {
+        if (r < rows_ok) {
+          OUT_STORE((obase + (size_t)r * ldo + cc * 8), v);
+          if constexpr (FP8) {
+            if (img8) {
               const float f0 = bf_lo(v.x), f1 = bf_hi(v.x), f2 = bf_lo(v.y), f3 = bf_hi(v.y);
               const float f4 = bf_lo(v.z), f5 = bf_hi(v.z), f6 = bf_lo(v.w), f7 = bf_hi(v.w);
               uint2 w;
@@ -950,10 +948,12 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
                                          fmaxf(fmaxf(fabsf(f4), fabsf(f5)), fmaxf(fabsf(f6), fabsf(f7)))));
             }
           }
-          if (p.q_amax) {
-            amax8 = wave_max(amax8);
-            if (lane == 0) atomic_max_abs(p.q_amax, amax8, blockIdx.x * 8 + uw);
-          }
+        }
+      }
+      if constexpr (FP8) {
+        if (img8 && p.q_amax) {
+          amax8 = wave_max(amax8);
+          if (lane == 0) atomic_max_abs(p.q_amax, amax8, blockIdx.x * 8 + uw);
         }
       }
     }
@@ -1103,7 +1103,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(PlbGemmNT p) {
             if constexpr (FP8 && ACT != 1) {
               if (want8) {   // form 7: the image is of gelu(u) (what the bf16 path's FFN output GEMM reads), not of the stash
                 const f32x4 z = ACT == 7 ? f32x4{bf_lo(gpk.x), bf_hi(gpk.x), bf_lo(gpk.y), bf_hi(gpk.y)} : v;
-                k8[mh][mi][nh][ni] = pack_fp8x4(z[0] * qs, z[1] * qs, z[2] * qs, z[3] * qs, p.c8_bf8 != 0);
+                k8[mh][mi][nh][ni] = pack_fp8x4(z[0] * qs, z[1] * qs, z[2] * qs, z[3] * qs, ACT == 7 ? false : ACT == 8 ? true : p.c8_bf8 != 0);
                 if (st) amax = fmaxf(amax, fmaxf(fmaxf(fabsf(z[0]), fabsf(z[1])), fmaxf(fabsf(z[2]), fabsf(z[3]))));
               }
             }

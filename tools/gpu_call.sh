@@ -1,7 +1,7 @@
 #!/bin/bash
-# One GPU call of round 4: fp8 vs bf16 convergence, soak, SQ counters of the fp8 step.
+# One GPU call of round 4: fp8 epilogue conversion changes A/B (fp8), bf16 sanity A/B, then the whole GPU suite.
 O=$PWD/gpurun_out/$1
 mkdir -p $O
-timeout -k 10 300 python tools/fp8_convergence.py 640 2e-4 > $O/fp8_convergence.txt 2>&1; echo "convergence rc=$?"; grep -v amdgpu $O/fp8_convergence.txt | tail -24
-timeout -k 10 300 python tools/soak.py 1500 > $O/soak_bf16.txt 2>&1; echo "soak rc=$?"; grep -v amdgpu $O/soak_bf16.txt | tail -5
-bash tools/sq_counters.sh ${1}_fp8 --dtype fp8 > $O/sq_fp8.log 2>&1; echo "sq rc=$?"; cp gpurun_out/sq_${1}_fp8/sq_counters.csv $O/sq_counters_fp8.csv; head -14 $O/sq_counters_fp8.csv | cut -c1-220
+python tools/step_ab.py --reps 3 --args "--dtype fp8" prev:PLBERT_HIP_LIB=plbert_amd/build/ab/lib_prev.so new > $O/ab_f8conv_fp8.txt 2>&1; tail -4 $O/ab_f8conv_fp8.txt
+python tools/step_ab.py --reps 2 prev:PLBERT_HIP_LIB=plbert_amd/build/ab/lib_prev.so new > $O/ab_f8conv_bf16.txt 2>&1; tail -4 $O/ab_f8conv_bf16.txt
+timeout -k 10 800 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; rc=$?; echo "pytest rc=$rc"; tail -5 $O/pytest_gpu.log
