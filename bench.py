@@ -202,7 +202,7 @@ def pmc_traffic(cls):
 
 
 def secondary_lines():
-    """BASELINE.json configs[3] and configs[4] beside the headline: short runs of this script as fresh child processes,
+    """BASELINE.json configs[3] and configs[4] (and both together) beside the headline: short runs of this script as fresh child processes,
     one after the other (a child is a new process with its own HIP context; nothing is exec'ed over this one). Each
     entry carries what its child's JSON line says; the parity tolerance of the fp8 path is part of the entry because it
     is NOT the north-star's 1e-3 (tests/test_gpu_fp8.py: no fp8 reference exists, parity is against this build's bf16
@@ -210,7 +210,7 @@ def secondary_lines():
     import subprocess
 
     out = {}
-    for key, extra in (("large", ["--model", "large"]), ("fp8", ["--dtype", "fp8"])):
+    for key, extra in (("large", ["--model", "large"]), ("fp8", ["--dtype", "fp8"]), ("large_fp8", ["--model", "large", "--dtype", "fp8"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "8", "--no-cpu-baseline",
                "--no-traffic", "--no-staged", "--no-secondary", *extra]
         try:
@@ -225,7 +225,7 @@ def secondary_lines():
                         "step_mfma_frac_wall": j["step_mfma_frac_wall"], "step_loss": j["step_loss"],
                         "workload": j["config"]["workload"], "dominant_kernel": rl.get("kernel"),
                         "dominant_frac": rl.get("frac"), "dominant_peak_TFLOPs": rl.get("peak")}
-            if key == "fp8":
+            if key.endswith("fp8"):
                 out[key]["parity"] = ("loss within 2e-2 relative of this build's bf16 path and of the reference; whole-gradient "
                                       "relative L2 0.10-0.11, per tensor <= 0.25 (tests/test_gpu_fp8.py, tools/fp8_diag.py) - NOT "
                                       "the 1e-3 of the bf16 path; no fp8 reference exists")
