@@ -441,3 +441,48 @@ def test_fp8_step_on_shapes_without_fused_layernorm_forms(B, S, lens):
     assert r < 0.2, r
     assert bool(torch.isfinite(eng.grads[:n]).all())
     assert eng.status()["ln_exchange_timeouts"] == 0
+
+
+def _fp8_vs_bf16(cfg, B, S, num_tokens=0, seed=5):
+    labels, masked, lens, idx = plbert_amd.synthetic_batch(B, S, seed=seed)
+    sd = plbert_amd.deterministic_state_dict(cfg, 188, num_tokens, seed=seed)
+    off, flat = plbert_amd.masked_indices_to_csr(idx)
+    tok = np.random.RandomState(seed).randint(0, num_tokens, size=(B, S)).astype(np.int64) if num_tokens else None
+    out = []
+    for fp8 in (False, True):
+        eng = HipEngine(cfg, 188, num_tokens, max_batch=B, max_seq=S)
+        eng.load_state_dict(sd)
+        if fp8:
+            eng.set_fp8(True)
+            eng.loss_fwd_bwd(masked, labels, None, off, flat, int(off[-1]), token_ids=tok)   # calibration
+        loss = float(eng.loss_fwd_bwd(masked, labels, None, off, flat, int(off[-1]), token_ids=tok).item())
+        torch.cuda.synchronize()
+        n = eng.total if num_tokens else eng.trainable
+        g = torch.cat([eng.grads[: eng.trainable], eng.grads[eng.token_range[0]:eng.token_range[1]]]) if num_tokens else eng.grads[:n]
+        out.append((loss, g.clone()))
+        del eng
+    return out
+
+
+def test_fp8_dual_head_step():
+    """MultiTaskModel step (phoneme + token loss) in fp8 mode: the encoder's GEMMs run on the images, the token head's
+    fused GEMM + cross-entropy passes stay bf16 and add their gradient into dH before the layer loop."""
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                                  max_position_embeddings=512, num_hidden_layers=4)
+    (l0, g0), (l1, g1) = _fp8_vs_bf16(cfg, 4, 512, num_tokens=1024)
+    assert l1 != l0 and abs(l1 - l0) / l0 < 2e-2, (l0, l1)
+    assert rel_l2(g1, g0) < 0.2 and bool(torch.isfinite(g1).all())
+
+
+def test_fp8_with_bf16_weight_gradient_operands(monkeypatch):
+    """PLBERT_FP8_TN=0: the fp8 step with the weight-gradient GEMMs on the bf16 stash (gelu(u), dU, dQKV then leave in both
+    forms) — the fall-back the engine also takes below the fp8 kernel's row minimum."""
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                                  max_position_embeddings=512, num_hidden_layers=12)
+    (l0, g0), (l1, g1) = _fp8_vs_bf16(cfg, 2, 512)
+    monkeypatch.setenv("PLBERT_FP8_TN", "0")
+    (_, _), (l2, g2) = _fp8_vs_bf16(cfg, 2, 512)
+    assert abs(l1 - l0) / l0 < 2e-2 and abs(l2 - l0) / l0 < 2e-2
+    assert rel_l2(g1, g0) < 0.2 and rel_l2(g2, g0) < 0.2
+    assert l1 == l2 and not torch.equal(g1, g2)        # same forward; the weight gradients come from other operands
+    assert rel_l2(g2, g1) < 0.1
