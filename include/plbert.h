@@ -163,7 +163,8 @@ int plb_adamw_step(PlbEngine* e, double lr, double beta1, double beta2, double e
  * binade of headroom); the first call after switching the mode on — and a training call whose gradient sites have not
  * been seen yet — runs in bf16 and only records the maxima. hidden_size 768 or 1024; calls whose GEMM shapes have no
  * pipeline-tile form run in bf16. The reference has no fp8 path (configs/config.yml:15: fp16 autocast): parity is against
- * this library's own bf16 path (tests/test_gpu_fp8.py: loss within 2e-2, whole-gradient relative L2 0.11). */
+ * this library's own bf16 path (tests/test_gpu_fp8.py: loss within 2e-2, whole-gradient relative L2 0.11) and against a
+ * CPU restatement of exactly these semantics on top of the pinned oracle (oracle/fp8_np.py). */
 int plb_set_fp8(PlbEngine* e, int32_t on, void* stream);
 int plb_fp8_state(const PlbEngine* e, int32_t* enabled, int32_t* calibrated);
 
