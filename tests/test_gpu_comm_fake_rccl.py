@@ -52,7 +52,7 @@ def _setup(num_tokens, real=False):
     return plbert_amd, cfg, (labels, masked, lengths, idx), tok
 
 
-def _worker(rank, world, port, lib, num_tokens, empty_rank, real, out):
+def _worker(rank, world, port, lib, num_tokens, empty_rank, real, fp8, out):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PLBERT_RCCL_LIB=lib, FAKE_RCCL_TIMEOUT_S="60")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     plbert_amd, cfg, batch, tok = _setup(num_tokens, real)
@@ -76,11 +76,15 @@ def _worker(rank, world, port, lib, num_tokens, empty_rank, real, out):
         assert tr.world == world and tr.comm == mode
         if mode == "rccl":
             assert tr.engine.comm_info() == (rank, world, 29999)          # the stand-in, not a real RCCL
+        if fp8:
+            tr.engine.set_fp8(True)                                         # step 1 calibrates (bf16), steps 2-3 run on the images
         b = tr.stage_batch(lab, msk, lens, ix, token_ids=tk)
         losses = [float(tr.step(b).item()) for _ in range(3)]
         torch.cuda.synchronize()
         assert tr.engine.status()["ln_exchange_timeouts"] == 0              # two processes share the GPU: hand-offs still arrive
         pieces = tr.engine.comm_pieces() if mode == "rccl" else None
+        if fp8:
+            assert tr.engine.fp8_state() == (True, True)
         res[(mode, overlap)] = (losses, tr.engine.params.cpu().numpy().copy(), pieces)
         if mode == "rccl":
             tr.engine.comm_destroy()
@@ -92,11 +96,11 @@ def _worker(rank, world, port, lib, num_tokens, empty_rank, real, out):
     dist.destroy_process_group()
 
 
-def _run_world2(lib, num_tokens=0, empty_rank=None, real=False):
+def _run_world2(lib, num_tokens=0, empty_rank=None, real=False, fp8=False):
     port = 29800 + (os.getpid() % 1500)
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_worker, args=(2, port, lib, num_tokens, empty_rank, real, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, port, lib, num_tokens, empty_rank, real, fp8, out), nprocs=2, join=True)
         return dict(out)
 
 
@@ -122,6 +126,14 @@ def test_piecewise_exchange_world2_on_the_bench_model(fake_lib):
     """The same on the model and launch forms the bench runs (768 / 12, 1024 tokens per rank: LayerNorm in the GEMM epilogues,
     gelu-derivative stash, big-tile weight-gradient GEMMs with the pieces issued between them)."""
     _check(_run_world2(fake_lib, real=True), expect_pieces_overlap=8)
+
+
+def test_piecewise_exchange_world2_fp8_calls(fake_lib):
+    """fp8 mode on the bench model: the pieces travel between the fp8 weight-gradient GEMMs (12 x 1024 stacked rows), each
+    rank quantises under its OWN delayed scales (the maxima are local; the weights' are identical), and the scale update
+    at the end of the call must not disturb the exchange — the replicas stay bit-identical to the gloo exchange of the
+    same fp8 steps, in the overlapped and in the serial form."""
+    _check(_run_world2(fake_lib, real=True, fp8=True), expect_pieces_overlap=8)
 
 
 def test_zero_masked_rank_issues_the_same_collectives(fake_lib):
