@@ -1279,7 +1279,7 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   // Q/K/V biases: the attention-backward kernels left the column sums of every 32-row patch they stored, per application
   // ([L][B*QT*4][3H])
   TRY(plb_launch_colsum(e->at<float>(e->o_qkvcol), 0, (size_t)L * (size_t)(B * ((S + 127) / 128) * 4), 3 * H, 3 * H, e->grd(PLB_Q_B),
-                        3 * H, 0, scratch2, 16, s2));
+                        3 * H, 0, scratch2, 64, s2));
   if (du_rows > 0)
     TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 16, s2));
   else

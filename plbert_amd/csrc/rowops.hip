@@ -125,6 +125,15 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(PlbEmbed p, int P) {
         const int n = wcnt[ww];
         const int* l = list + ww * cap;
         int i = grp;
+        for (; i + 7 * ngrp < n; i += 8 * ngrp) {   // the mask id owns ~12 % of the tokens: its block is the launch's duration
+          float4 v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = *(const float4*)(p.dx + (size_t)l[i + k * ngrp] * E + 4 * q);
+          s.x += ((v[0].x + v[1].x) + (v[2].x + v[3].x)) + ((v[4].x + v[5].x) + (v[6].x + v[7].x));
+          s.y += ((v[0].y + v[1].y) + (v[2].y + v[3].y)) + ((v[4].y + v[5].y) + (v[6].y + v[7].y));
+          s.z += ((v[0].z + v[1].z) + (v[2].z + v[3].z)) + ((v[4].z + v[5].z) + (v[6].z + v[7].z));
+          s.w += ((v[0].w + v[1].w) + (v[2].w + v[3].w)) + ((v[4].w + v[5].w) + (v[6].w + v[7].w));
+        }
         for (; i + 3 * ngrp < n; i += 4 * ngrp) {
           const int t0 = l[i], t1 = l[i + ngrp], t2 = l[i + 2 * ngrp], t3 = l[i + 3 * ngrp];
           const float4 v0 = *(const float4*)(p.dx + (size_t)t0 * E + 4 * q), v1 = *(const float4*)(p.dx + (size_t)t1 * E + 4 * q);
@@ -606,6 +615,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const void* X, size_t R, in
         acc[7] += (bf_hi(u0.w) + bf_hi(u1.w)) + (bf_hi(u2.w) + bf_hi(u3.w));
       }
     }
+    if (!BF16) {  // fp32 partial rows (attention / GEMM epilogue column sums): 8 independent 16-B loads in flight per thread
+      const float* px = (const float*)X + c;
+      for (; r + 24 < r1; r += 32) {
+        const float* q0 = px + r * ld;
+        const float* q1 = px + (r + 8) * ld;
+        const float* q2 = px + (r + 16) * ld;
+        const float* q3 = px + (r + 24) * ld;
+        const float4 a0 = *(const float4*)q0, b0 = *(const float4*)(q0 + 4), a1 = *(const float4*)q1, b1 = *(const float4*)(q1 + 4);
+        const float4 a2 = *(const float4*)q2, b2 = *(const float4*)(q2 + 4), a3 = *(const float4*)q3, b3 = *(const float4*)(q3 + 4);
+        acc[0] += (a0.x + a1.x) + (a2.x + a3.x); acc[1] += (a0.y + a1.y) + (a2.y + a3.y);
+        acc[2] += (a0.z + a1.z) + (a2.z + a3.z); acc[3] += (a0.w + a1.w) + (a2.w + a3.w);
+        acc[4] += (b0.x + b1.x) + (b2.x + b3.x); acc[5] += (b0.y + b1.y) + (b2.y + b3.y);
+        acc[6] += (b0.z + b1.z) + (b2.z + b3.z); acc[7] += (b0.w + b1.w) + (b2.w + b3.w);
+      }
+    }
     for (; r < r1; r += 8) {
       if (BF16) {
         uint4 u = *(const uint4*)((const bf16_t*)X + r * ld + c);
@@ -659,18 +683,27 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slab, in
   }
 }
 
+// 32 columns per block (one 128-byte line per split row), 8 thread groups over the splits with 4 independent partial sums
+// each: a column's sum is two dependent memory round trips deep, not nsplit / 4 (these launches sit on the side stream
+// beside the weight-gradient GEMMs: at 10-15 us each, nine of them were a quarter of its busy time). Fixed order per column.
 __global__ __launch_bounds__(256) void reduce_cols_kernel(const float* scratch, int nsplit, int N, int Nout, float* out,
                                                           int accumulate, int col0) {
-  __shared__ float red[4][64];
-  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int j = blockIdx.x * 64 + c;
-  float s = 0.f;
-  if (j < Nout)
-    for (int k = g; k < nsplit; k += 4) s += scratch[(size_t)k * N + col0 + j];  // fixed order per column
-  red[g][c] = s;
+  __shared__ float red[8][32];
+  const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (j < Nout) {
+    const float* px = scratch + col0 + j;
+    int k = g;
+    for (; k + 24 < nsplit; k += 32) {
+      s0 += px[(size_t)k * N]; s1 += px[(size_t)(k + 8) * N]; s2 += px[(size_t)(k + 16) * N]; s3 += px[(size_t)(k + 24) * N];
+    }
+    for (; k < nsplit; k += 8) s0 += px[(size_t)k * N];
+  }
+  red[g][c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (g == 0 && j < Nout) {
-    const float t = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    const float t = ((red[0][c] + red[1][c]) + (red[2][c] + red[3][c])) + ((red[4][c] + red[5][c]) + (red[6][c] + red[7][c]));
     out[j] = accumulate ? out[j] + t : t;
   }
 }
@@ -1060,7 +1093,7 @@ extern "C" int plb_launch_colsum(const void* X, int is_bf16, size_t R, int N, in
   if (is_bf16) hipLaunchKernelGGL((colsum_kernel<true>), grid, dim3(256), 0, stream, X, R, N, ld, scratch, nsplit);
   else hipLaunchKernelGGL((colsum_kernel<false>), grid, dim3(256), 0, stream, X, R, N, ld, scratch, nsplit);
   if (hipGetLastError() != hipSuccess) return 2;
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)((Nout + 63) / 64)), dim3(256), 0, stream, scratch, nsplit, N,
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)((Nout + 31) / 32)), dim3(256), 0, stream, scratch, nsplit, N,
                      Nout, out, accumulate, 0);
   return LAUNCH_OK();
 }
@@ -1069,7 +1102,7 @@ extern "C" int plb_launch_colsum(const void* X, int is_bf16, size_t R, int N, in
 extern "C" int plb_launch_copy_cols(const float* scratch, int nsplit, int N, int col0, int Nout, float* out,
                                     hipStream_t stream) {
   if (nsplit <= 0 || col0 < 0 || col0 + Nout > N) return 1;
-  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)((Nout + 63) / 64)), dim3(256), 0, stream, scratch, nsplit, N,
+  hipLaunchKernelGGL(reduce_cols_kernel, dim3((unsigned)((Nout + 31) / 32)), dim3(256), 0, stream, scratch, nsplit, N,
                      Nout, out, 0, col0);
   return LAUNCH_OK();
 }
