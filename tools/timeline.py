@@ -42,6 +42,15 @@ def main():
     for g in gaps[-8:]:
         print(f"{g[0]:8.1f}  {g[1]} -> {g[2]}")
     print(f"sum of main-queue gaps: {sum(g[0] for g in gaps) / 1e3:.3f} ms over {len(gaps)} boundaries")
+    # the step by kernel name and queue: launches, total and mean duration
+    import collections
+    by = collections.defaultdict(lambda: [0, 0.0])
+    for s, e, q, n in step:
+        by[(q, n)][0] += 1
+        by[(q, n)][1] += (e - s) / 1e3
+    print("--- the step by kernel (queue, launches, total us, mean us):")
+    for (q, n), (c, t) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+        print(f"  q{q} {c:4d} {t:9.1f} {t / c:8.1f}  {n}")
 
 
 if __name__ == "__main__":
