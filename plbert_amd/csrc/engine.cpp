@@ -568,10 +568,10 @@ static int fp8_update_scales(PlbEngine* e, hipStream_t s) {
   const int L = e->L;
   // One scale per SITE, shared by its L applications (their maxima are recorded per application): the weight-gradient
   // GEMMs sum the products of two images over all applications under one dequantisation factor.
-  TRY(plb_launch_fp8_scales(f8_amax(e, 0), f8_scale(e, 0), f8_deq(e, 0), 4 * L, 448.f, L, s));                // X, A, G, C: e4m3
-  // Gradients: e5m2, mapped to HALF the format's range — a step whose gradients are up to 2x the previous step's (a smaller
-  // batch: the loss is a mean over samples) still fits; five exponent bits have the binade to spare.
-  TRY(plb_launch_fp8_scales(f8_amax(e, 4 * L), f8_scale(e, 4 * L), f8_deq(e, 4 * L), 4 * L, 28672.f, L, s));  // DP, DU, DP1, DQ
+  // X, A, G, C: e4m3, 448. Gradients (DP, DU, DP1, DQ): e5m2, mapped to HALF the format's range — a step whose gradients
+  // are up to 2x the previous step's (a smaller batch: the loss is a mean over samples) still fits; five exponent bits
+  // have the binade to spare. One launch for the whole site table.
+  TRY(plb_launch_fp8_scales2(f8_amax(e, 0), f8_scale(e, 0), f8_deq(e, 0), 8 * L, 448.f, L, 4 * L, 28672.f, s));
   return 0;
 }
 
@@ -588,16 +588,19 @@ static int sync_transposes(PlbEngine* e, hipStream_t s, bool exact_fp8 = true) {
     return 0;
   }
   // fused QKV [3H,H] -> [H,3H]; the three tensors are adjacent in the flat buffer
-  TRY(plb_launch_transpose_cast(e->par(PLB_Q_W), 3 * H, H, e->at<bf16_t>(e->o_wqkvT), 3 * H, s));
-  TRY(plb_launch_transpose_cast(e->par(PLB_DENSE_W), H, H, e->at<bf16_t>(e->o_wdT), H, s));
-  TRY(plb_launch_transpose_cast(e->par(PLB_FFN_W), I, H, e->at<bf16_t>(e->o_w1T), I, s));
-  TRY(plb_launch_transpose_cast(e->par(PLB_FFNO_W), H, I, e->at<bf16_t>(e->o_w2T), H, s));
-  TRY(plb_launch_transpose_cast(e->par(PLB_HEAD_W), e->NP, H, e->at<bf16_t>(e->o_wpT), 256, s));
-  TRY(plb_launch_transpose_cast(e->par(PLB_MAP_W), H, E, e->at<bf16_t>(e->o_winT), H, s));
+  // (one launch for all of them: each is a few microseconds of work behind 5 us of launch latency)
+  const float* tsrc[8] = {e->par(PLB_Q_W), e->par(PLB_DENSE_W), e->par(PLB_FFN_W), e->par(PLB_FFNO_W), e->par(PLB_HEAD_W),
+                          e->par(PLB_MAP_W)};
+  bf16_t* tdst[8] = {e->at<bf16_t>(e->o_wqkvT), e->at<bf16_t>(e->o_wdT), e->at<bf16_t>(e->o_w1T), e->at<bf16_t>(e->o_w2T),
+                     e->at<bf16_t>(e->o_wpT), e->at<bf16_t>(e->o_winT)};
+  int tR[8] = {3 * H, H, I, H, e->NP, H}, tC[8] = {H, H, H, I, H, E}, tld[8] = {3 * H, H, I, H, 256, H};
+  int nt = 6;
   if (e->NT) {  // transposed weight of the token head, padded to NTp columns
     if (!e->tok_pad_zeroed) HIPTRY(hipMemsetAsync(e->at<bf16_t>(e->o_wtT), 0, (size_t)rup(H, 128) * e->NTp * 2, s));
-    TRY(plb_launch_transpose_cast(e->par(PLB_TOK_W), e->NT, H, e->at<bf16_t>(e->o_wtT), e->NTp, s));
+    tsrc[nt] = e->par(PLB_TOK_W); tdst[nt] = e->at<bf16_t>(e->o_wtT); tR[nt] = e->NT; tC[nt] = H; tld[nt] = e->NTp;
+    ++nt;
   }
+  TRY(plb_launch_transpose_cast_multi(nt, tsrc, tR, tC, tdst, tld, s));
   e->tok_pad_zeroed = true;
   if (e->fp8_on) return fp8_quantize_weights(e, s, exact_fp8 || e->fp8_wstale);
   return 0;
@@ -721,8 +724,11 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
   g.bias = e->par(PLB_MAP_B); g.C = xall; g.ldc = H;
   TRY(plb_launch_gemm_nt(&g, 0, 0, s));
   if (f8) {  // layer 0 reads the map-in output, which no LayerNorm produced: one quantisation pass
-    TRY(plb_launch_quantize(xall, 1, (size_t)T, H, H, f8_scale(e, f8_site(e, F8_X, 0)), e->at<uint8_t>(e->o_x8), H, 0, s));
-    TRY(plb_launch_amax(xall, 1, (size_t)T, H, H, f8_amax(e, f8_site(e, F8_X, 0)), s));
+    // (image and the site's maximum in one pass: the rows are contiguous)
+    const void* src1[1] = {xall}; const int bf1[1] = {1}; const size_t n1[1] = {(size_t)T * H};
+    const float* sc1[1] = {f8_scale(e, f8_site(e, F8_X, 0))}; uint8_t* dst1[1] = {e->at<uint8_t>(e->o_x8)};
+    float* am1[1] = {f8_amax(e, f8_site(e, F8_X, 0))};
+    TRY(plb_launch_quantize_multi(1, src1, bf1, n1, sc1, dst1, am1, s));
   }
   const bool fuse_f = ln_fusable(e, Tp, 1);
   const bool dstash = gelu_dstash(e, Tp, f8);

@@ -151,6 +151,9 @@ typedef struct {
 int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols, int ld, float* amax, hipStream_t stream);
 // group: runs of `group` consecutive sites share one scale (from the largest maximum of the run); 1 = every site its own
 int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, int group, hipStream_t stream);
+// the same with a second target for entries [n2, n) (n2 a multiple of group)
+int plb_launch_fp8_scales2(float* amax, float* scale, float* deq, int n, float fmax, int group, int n2, float fmax2,
+                           hipStream_t stream);
 int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int cols, int ld, const float* scale, uint8_t* out, int ldo,
                         int bf8, hipStream_t stream);
 // the fp8 copies of up to 8 contiguous weight matrices in one launch: dst[i] = e4m3(src[i] * scale[i][0]); amax[i] (a site)
@@ -261,6 +264,8 @@ int plb_launch_step_status(const unsigned int* ln_err, float* loss, unsigned int
 int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream);
 // dst[c, r] = bf16(src[r, c]) for r<R, c<C ; dst has ldd >= R columns (zero fill is the caller's job)
 int plb_launch_transpose_cast(const float* src, int R, int C, bf16_t* dst, int ldd, hipStream_t stream);
+int plb_launch_transpose_cast_multi(int n, const float* const* src, const int* R, const int* C, bf16_t* const* dst,
+                                    const int* ldd, hipStream_t stream);
 int plb_launch_bf16_to_f32(const bf16_t* src, int lds_, float* dst, int ldd, int R, int C, hipStream_t stream);
 
 }  // extern "C"

@@ -880,6 +880,29 @@ __global__ void transpose_cast_kernel(const float* src, int R, int C, bf16_t* ds
     if (c < C && r < R) dst[(size_t)c * ldd + r] = f2bf(tile[tx][k]);
   }
 }
+// Up to 8 transposes in ONE launch (the six weight copies the backward reads are 5 us of launch latency each after every
+// optimizer step): block b belongs to the matrix whose tile range contains it.
+struct TransposeMulti { const float* src[8]; bf16_t* dst[8]; int R[8], C[8], ldd[8], first[9]; int n; };
+__global__ __launch_bounds__(256) void transpose_cast_multi_kernel(TransposeMulti q) {
+  __shared__ float tile[32][33];
+  int w = 0;
+  while (w + 1 < q.n && (int)blockIdx.x >= q.first[w + 1]) ++w;
+  const int R = q.R[w], C = q.C[w], ldd = q.ldd[w];
+  const int tiles_c = (C + 31) / 32, b = blockIdx.x - q.first[w];
+  const int c0 = (b % tiles_c) * 32, r0 = (b / tiles_c) * 32;
+  const float* src = q.src[w];
+  bf16_t* dst = q.dst[w];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    tile[k][tx] = (r < R && c < C) ? src[(size_t)r * C + c] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int c = c0 + k, r = r0 + tx;
+    if (c < C && r < R) dst[(size_t)c * ldd + r] = f2bf(tile[tx][k]);
+  }
+}
 // ------------------------------------------------------------------------------------ fp8 plumbing
 // max |x| over a [rows][cols] matrix (ld elements per row) into one device scalar: per-thread 16-byte strides, wave
 // shuffle, one atomic per wave. cols % 8 == 0 (bf16) / % 4 == 0 (fp32).
@@ -911,9 +934,11 @@ __global__ __launch_bounds__(256) void amax_kernel(const void* X, size_t rows, i
 // group > 1: sites come in runs of `group` entries (the L applications of the shared layer at one operand site) that share
 // ONE scale, formed from the largest maximum of the run — the weight-gradient GEMM sums products of two images over all
 // applications in one launch with one dequantisation factor, so every application's image must be on the same scale.
-__global__ __launch_bounds__(64) void fp8_scales_kernel(float* amax, float* scale, float* deq, int n, float fmax, int group) {
+__global__ __launch_bounds__(64) void fp8_scales_kernel(float* amax, float* scale, float* deq, int n, float fmax, int group,
+                                                        int n2, float fmax2) {
   const int g0 = blockIdx.x * group, lane = threadIdx.x;
   if (g0 >= n) return;
+  if (g0 >= n2) fmax = fmax2;   // entries [n2, n): the second format's target (one launch for both halves of the site table)
   float a = 0.f;
   for (int i = g0; i < g0 + group && i < n; ++i) {
     float* w = amax + (size_t)i * F8_SLOTS * F8_STRIDE + lane * F8_STRIDE;
@@ -1178,6 +1203,23 @@ extern "C" int plb_launch_transpose_cast(const float* src, int R, int C, bf16_t*
   hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, stream, src, R, C, dst, ldd);
   return LAUNCH_OK();
 }
+// dst[i][c][r] = bf16(src[i][r][c]) for n <= 8 matrices (R[i] x C[i], dst rows ldd[i] elements apart) in one launch
+extern "C" int plb_launch_transpose_cast_multi(int n, const float* const* src, const int* R, const int* C, bf16_t* const* dst,
+                                               const int* ldd, hipStream_t stream) {
+  if (n < 1 || n > 8) return 1;
+  TransposeMulti q = {};
+  double bytes = 0;
+  q.n = n;
+  for (int i = 0; i < n; ++i) {
+    if (!src[i] || !dst[i] || R[i] < 1 || C[i] < 1 || ldd[i] < R[i]) return 1;
+    q.src[i] = src[i]; q.dst[i] = dst[i]; q.R[i] = R[i]; q.C[i] = C[i]; q.ldd[i] = ldd[i];
+    q.first[i + 1] = q.first[i] + ((R[i] + 31) / 32) * ((C[i] + 31) / 32);
+    bytes += 6.0 * (double)R[i] * C[i];
+  }
+  ProfScope ps(PLB_K_CAST, stream, 0, bytes);
+  hipLaunchKernelGGL(transpose_cast_multi_kernel, dim3(q.first[n]), dim3(256), 0, stream, q);
+  return LAUNCH_OK();
+}
 extern "C" int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols, int ld, float* amax, hipStream_t stream) {
   if (!rows || cols <= 0 || cols % 8 || ld % 8) return 1;
   const size_t n = rows * (size_t)(cols / (is_bf16 ? 8 : 4));
@@ -1187,11 +1229,15 @@ extern "C" int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols
   else hipLaunchKernelGGL((amax_kernel<false>), dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld, amax);
   return LAUNCH_OK();
 }
-extern "C" int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, int group, hipStream_t stream) {
+extern "C" int plb_launch_fp8_scales2(float* amax, float* scale, float* deq, int n, float fmax, int group, int n2, float fmax2,
+                                      hipStream_t stream) {
   if (n <= 0) return 0;
   if (group < 1) group = 1;
-  hipLaunchKernelGGL(fp8_scales_kernel, dim3((n + group - 1) / group), dim3(64), 0, stream, amax, scale, deq, n, fmax, group);
+  hipLaunchKernelGGL(fp8_scales_kernel, dim3((n + group - 1) / group), dim3(64), 0, stream, amax, scale, deq, n, fmax, group, n2, fmax2);
   return LAUNCH_OK();
+}
+extern "C" int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, int group, hipStream_t stream) {
+  return plb_launch_fp8_scales2(amax, scale, deq, n, fmax, group, n, fmax, stream);
 }
 extern "C" int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int cols, int ld, const float* scale,
                                    uint8_t* out, int ldo, int bf8, hipStream_t stream) {
@@ -1215,7 +1261,7 @@ extern "C" int plb_launch_quantize_multi(int n, const void* const* src, const in
     bytes += elements[i] * (is_bf16[i] ? 3 : 5);
   }
   ProfScope ps(PLB_K_FP8, stream, 0, (double)bytes);
-  hipLaunchKernelGGL(quantize_multi_kernel, dim3(128, n), dim3(256), 0, stream, q);
+  hipLaunchKernelGGL(quantize_multi_kernel, dim3(n == 1 ? 1024 : 128, n), dim3(256), 0, stream, q);   // one matrix: the whole chip
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_pooler(const float* hidden, int B, int S, int H, const float* W, const float* bias, float* pooled,
