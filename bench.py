@@ -79,6 +79,11 @@ def parse():
     ap.add_argument("--no-staged", action="store_true", help="skip the per-step-staging re-run")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the short child runs of BASELINE.json configs[3] (--model large) and configs[4] (--dtype fp8)")
+    ap.add_argument("--pipeline-workers", type=int, default=None,
+                    help="child mode of secondary.pipeline: feed the step from the REAL input pipeline (synthetic documents -> "
+                         "build_dataloader(num_workers=N, decisions=True) -> DeviceFeeder -> PLBertTrainer.step) and print its "
+                         "own JSON line (ms/step beside the resident-batch step of the same process)")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the secondary.pipeline child runs")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
                     help="fp8 = BASELINE configs[4], a separately reported workload: the QKV / FFN GEMMs (forward and FFN "
                          "dX) on e4m3 / e5m2 operands through the block-scaled MFMA, everything else as in bf16")
@@ -224,7 +229,8 @@ def secondary_lines():
             out[key] = {"ms_per_step": j["ms_per_step"], "value": j["value"], "unit": j["unit"],
                         "step_mfma_frac_wall": j["step_mfma_frac_wall"], "step_loss": j["step_loss"],
                         "workload": j["config"]["workload"], "dominant_kernel": rl.get("kernel"),
-                        "dominant_frac": rl.get("frac"), "dominant_peak_TFLOPs": rl.get("peak")}
+                        "dominant_frac": rl.get("frac"), "dominant_peak_TFLOPs": rl.get("peak"),
+                        "loss_parity": j.get("loss_parity")}
             if key.endswith("fp8"):
                 out[key]["parity"] = ("loss within 2e-2 relative of this build's bf16 path and of the reference; whole-gradient "
                                       "relative L2 0.10-0.11, per tensor <= 0.25 (tests/test_gpu_fp8.py, tools/fp8_diag.py) - NOT "
@@ -232,6 +238,157 @@ def secondary_lines():
         except Exception as ex:  # the headline line must still be printed
             out[key] = {"error": repr(ex)}
     return out
+
+
+PIPELINE_WORKERS = (0, 4, 8, 16)
+
+
+def synthetic_documents(n_docs, seed=77):
+    """Rows of {'phonemes': [words]} the way the reference's dataset holds them (train.py:245: lists of phonemised words):
+    100-130 words of 3-7 characters over the phoneme letters = 520-900 positions with separators, so every sample is
+    cropped to max_seq_length 512 (dataloader.py:110-126) and a batch is the bench's 32 x 512."""
+    import plbert_amd
+    rs = np.random.RandomState(seed)
+    letters = np.array(list(plbert_amd.symbols[52:185]))
+    docs = []
+    for _ in range(n_docs):
+        lens = rs.randint(3, 8, size=int(rs.randint(100, 131)))
+        chars = letters[rs.randint(0, len(letters), size=int(lens.sum()))]
+        words, o = [], 0
+        for n in lens:
+            words.append("".join(chars[o:o + n]))
+            o += n
+        docs.append({"phonemes": words})
+    return docs
+
+
+def pipeline_child(args):
+    """secondary.pipeline, one worker count: the step fed by the real input pipeline (the
+    reference: DataLoader(num_workers=0), train.py:253, Python masking in dataloader.py:35-142 on the training thread)."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    N = args.pipeline_workers
+    import torch
+    import plbert_amd
+    from plbert_amd import data as pdata
+    from plbert_amd.pipeline import DeviceFeeder
+    from plbert_amd.train import PLBertTrainer
+
+    B, S, steps, warm = args.batch, args.seq, args.steps, max(args.warmup, 10)
+    docs = synthetic_documents((steps + warm + 8) * B * 100 // 95 + B)
+    params = dict(word_separator=87, word_pred_prob=0.15, phoneme_mask_prob=0.8, replace_prob=0.1, max_seq_length=S)
+    torch.manual_seed(5)
+    pdata.seed_reference_streams(1)
+    kw = dict(prefetch_factor=4) if N else {}
+    loader, _ = plbert_amd.build_dataloader(docs, batch_size=B, device="cuda", dataset_config=params, use_token_ids=False,
+                                            num_workers=N, decisions=True, **kw)
+    # producer alone (no GPU in this process yet: the worker processes are forked before the HIP runtime exists)
+    it = iter(loader)
+    next(it)
+    t0, n = time.perf_counter(), 0
+    while time.perf_counter() - t0 < 3.0:
+        next(it)
+        n += 1
+    producer = n * B / (time.perf_counter() - t0)
+    del it
+    cfg = plbert_amd.AlbertConfig(vocab_size=len(plbert_amd.symbols), hidden_size=768, num_attention_heads=12,
+                                  intermediate_size=2048, max_position_embeddings=512, num_hidden_layers=12)
+    trainer = PLBertTrainer(cfg, num_phonemes=len(plbert_amd.symbols), max_batch=B, max_seq=S, lr=7e-5, device="cuda:0", seed=0)
+    if args.dtype == "fp8":
+        trainer.engine.set_fp8(True)
+    batch = trainer.stage_batch(*plbert_amd.synthetic_batch(B, S, seed=1234))
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+
+    def resident(k):
+        for _ in range(k):
+            trainer.step(batch)
+    resident(20)
+    t_res = timed(lambda: resident(50)) / 50
+    res = {}
+    for on_copy in ((True, False) if N == 8 else (True,)):   # one A/B of where the device-side masking runs
+        feeder = DeviceFeeder(loader, device=trainer.engine.device, vocab_size=cfg.vocab_size, word_separator=87,
+                              mask_on_copy_stream=on_copy)
+        it = iter(feeder)
+        tokens = [0]
+
+        def fed(k):
+            for _ in range(k):
+                b = next(it)
+                tokens[0] += b.n_tokens
+                trainer.step(b)
+        fed(warm)
+        tokens[0] = 0
+        t = timed(lambda: fed(steps))
+        res[on_copy] = (t / steps, tokens[0] / t)
+        it.close()
+    assert trainer.engine.status()["ln_exchange_timeouts"] == 0
+    t_pipe, rate = res[True]
+    out = {"workers": N, "dtype": args.dtype, "ms_per_step": round(t_pipe * 1e3, 3), "tokens_per_s": round(rate, 1),
+           "resident_ms_per_step": round(t_res * 1e3, 3), "ratio_to_resident": round(t_res / t_pipe, 4),
+           "producer_alone_samples_per_s": round(producer, 1),
+           "producer_alone_samples_per_s_per_worker": round(producer / max(N, 1), 1),
+           "steps": steps, "host_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
+    if False in res:
+        out["mask_on_compute_stream_ms_per_step"] = round(res[False][0] * 1e3, 3)
+    os.dup2(real_stdout, 1)
+    print(json.dumps(out), flush=True)
+    os._exit(0)   # worker processes of a persistent DataLoader: do not wait for their teardown
+
+
+def pipeline_lines():
+    """secondary.pipeline: the step fed by the REAL input pipeline for N worker processes in PIPELINE_WORKERS, bf16 and
+    fp8, each a fresh child process (fork of the loader's workers happens before that child touches the GPU)."""
+    import subprocess
+    out = {"how": "synthetic documents (100-130 words, cropped to 512) -> build_dataloader(batch 32, num_workers=N, "
+                  "decisions=True): workers draw the reference's masking decisions -> DeviceFeeder: one pinned buffer + one "
+                  "async copy per batch, plb_apply_mask on the copy stream -> PLBertTrainer.step; 100 timed steps; "
+                  "ratio_to_resident = resident-batch step of the same process / fed step"}
+    for dtype in ("bf16", "fp8"):
+        rows = []
+        for n in PIPELINE_WORKERS:
+            cmd = [sys.executable, os.path.abspath(__file__), "--pipeline-workers", str(n), "--dtype", dtype, "--steps", "100",
+                   "--warmup", "10"]
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=180, text=True)
+                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+                rows.append(json.loads(line[-1]) if r.returncode == 0 and line else {"workers": n, "error": f"rc {r.returncode}"})
+            except Exception as ex:
+                rows.append({"workers": n, "error": repr(ex)})
+        ok = [r["workers"] for r in rows if r.get("ratio_to_resident", 0) >= 0.97]
+        out[dtype] = {"runs": rows, "min_workers_for_0.97_of_resident": min(ok) if ok else None}
+    return out
+
+
+def loss_parity(trainer, batch, args, world, B, S):
+    """The metric's LOSS half at the size it is quoted on: the first steps of this very run — fresh reference-initialised
+    weights (seed 0), rank 0's batch synthetic_batch(B, 512, seed=1234), AdamW lr 7e-5 — against the loss trajectory the
+    REFERENCE produced on the same inputs in the build container (tests/golden/real_s512_b32.npz / real_h1024_s512_b16.npz,
+    captured by oracle/gen_golden.py fullsize_a / fullsize_d from /root/reference's process_batch + torch AdamW; data
+    fixtures, nothing of the reference runs here). N > 1: the ranks' batches differ, so only the first loss (before any
+    update) is comparable. Called before anything else has stepped the trainer; returns the JSON entry (rank 0) or None."""
+    name = {"base": "real_s512_b32", "large": "real_h1024_s512_b16"}[args.model]
+    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+    if args.num_tokens or S != 512 or not os.path.exists(path):
+        return None
+    g = np.load(path, allow_pickle=True)
+    if g["labels"].shape != (B, S):
+        return None
+    ref = [float(x) for x in g["losses"]]
+    n = len(ref) if world == 1 else 1
+    got = [float(trainer.step(batch).item()) for _ in range(n)]
+    rel = [abs(a - b) / abs(b) for a, b in zip(got, ref)]
+    tol = 1e-3 if args.dtype == "bf16" else 2e-2
+    return {"fixture": f"tests/golden/{name}.npz (reference process_batch + AdamW on bench.py's rank-0 inputs)",
+            "ref": [round(x, 6) for x in ref[:n]], "got": [round(x, 6) for x in got], "max_rel": float(f"{max(rel):.3e}"),
+            "tol": tol, "ok": bool(max(rel) <= tol), "steps_compared": n,
+            "note": None if args.dtype == "bf16" else "fp8 call: step 1 is the bf16 calibration call; tolerance is the mode's own 2e-2"}
 
 
 class StagedFeeder:
@@ -305,6 +462,8 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec 
 
 def main():
     args = parse()
+    if args.pipeline_workers is not None:
+        pipeline_child(args)     # never returns
     if args.gpus > 1 and "RANK" not in os.environ:
         launch_ranks(args.gpus)  # never returns
     # The contract is ONE JSON line on stdout. Native libraries write there too (RCCL prints a version banner
@@ -402,6 +561,10 @@ def main():
         token_ids = np.random.RandomState(4321 + rank).randint(0, args.num_tokens, size=(B, S)).astype(np.int64)
         model_desc += f" + token head {args.num_tokens}"
     batch = trainer.stage_batch(labels, masked, lengths, idx, token_ids=token_ids)  # resident in HBM before timing
+    # the run's first steps from fresh weights against the reference's own trajectory on the same inputs (untimed)
+    parity = loss_parity(trainer, batch, args, world, B, S)
+    if parity is not None and rank != 0:
+        parity = None
 
     def sync_all():
         torch.cuda.synchronize()
@@ -479,6 +642,35 @@ def main():
     if trainer.comm == "rccl":  # which form of the exchange the timed steps really ran
         n_coll, n_floats = eng.comm_pieces()
         comm_info.update(pieces_per_step=n_coll, floats_per_step=n_floats)
+        # Self-diagnosis of an N > 1 run, readable from this one line: (a) per piece, when it was released (the launch that
+        # completed its range had finished) and when its all-reduce had finished, in ms since the step's first launch,
+        # beside begin / end of the weight-gradient tail — a piece that finishes long after tail_ms[1] is what the step
+        # waits for; (b) the tail's weight-gradient GEMM time with the exchange running beside it (here) and without
+        # (roofline.kernel_ms_per_step, measured after the communicator is gone): RCCL-vs-GEMM CU contention.
+        if overlap_choice:
+            eng.comm_trace(True)
+            run_steps(3)
+            tr = eng.comm_trace_read()
+            eng.comm_trace(False)
+            names = {0: "embeddings+map-in+LN2", eng.layout["phoneme_predictor.weight"][0]: "phoneme head"}
+            for k in ("query.weight", "query.bias", "ffn.weight", "ffn.bias", "ffn_output.weight", "ffn_output.bias"):
+                full = "encoder.encoder.albert_layer_groups.0.albert_layers.0." + ("attention." if k.startswith("query") else "") + k
+                names[eng.layout[full][0]] = {"query.weight": "Q/K/V weights", "query.bias": "QKV biases+dense+LN1", "ffn.weight": "ffn.weight",
+                                              "ffn.bias": "ffn.bias", "ffn_output.weight": "ffn_output.weight",
+                                              "ffn_output.bias": "ffn_output.bias"}[k]
+            for pc in tr["pieces"]:
+                pc["what"] = names.get(pc["range"][0], "token head" if pc["range"][0] > eng.trainable else "?")
+                pc["MB"] = round((pc["range"][1] - pc["range"][0]) * 4 / 1e6, 2)
+                pc["lag_ms"] = round(pc["done_ms"] - pc["released_ms"], 4)
+            comm_info["piece_trace"] = tr
+            _lib.profile_enable(True)
+            run_steps(5)
+            torch.cuda.synchronize()
+            pr = _lib.profile_read()
+            _lib.profile_enable(False)
+            tn = [v for k, v in pr.items() if k.startswith("gemm_tn")]
+            comm_info["tail_gemm_tn_ms_with_exchange"] = round(max_over_ranks(sum(v["ms"] for v in tn) / 5), 4)
+            comm_info["tn_cus"] = int(os.environ.get("PLBERT_TN_CUS", "256"))
 
     # ---- the same K steps with a fresh batch staged every step (H2D inside the timed region) -------------------
     staged = None
@@ -543,6 +735,8 @@ def main():
         _lib.profile_enable(False)
         if rank == 0 and prof:
             total_ms = sum(v["ms"] for v in prof.values())
+            if "tail_gemm_tn_ms_with_exchange" in comm_info:
+                comm_info["tail_gemm_tn_ms_without_exchange"] = round(sum(v["ms"] for k, v in prof.items() if k.startswith("gemm_tn")) / args.steps, 4)
             # The dominant KERNEL is the NT pipeline GEMM (csrc/gemm_nt_pipeline.h: one template, one K loop); the
             # profiler files its launches under one class per epilogue form. They are summed here — taking the largest
             # single class would hand the title to the weight-gradient kernel the moment an epilogue form (LayerNorm
@@ -604,6 +798,8 @@ def main():
     if (rank == 0 and world == 1 and not dist.is_initialized() and not args.no_secondary and args.model == "base"
             and args.dtype == "bf16" and not args.num_tokens and args.batch == 32 and args.seq == 512):
         secondary = secondary_lines()
+        if not args.no_pipeline:
+            secondary["pipeline"] = pipeline_lines()
 
     if rank == 0:
         tokens = world * B * S * args.steps
@@ -617,6 +813,7 @@ def main():
                        "global_batch": world * B, "seq_len": S, "parallelism": f"dp{world}"},
             "step_loss": round(loss_val, 5),
             "step_mfma_frac_wall": round(flop_per_token * B * S / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "loss_parity": parity,
             "ranks_seen": ranks_seen, "comm": comm_info, "staged": staged,
             # in-launch hand-offs of the LayerNorm-in-GEMM kernels that timed out over the whole run: must be 0
             "ln_exchange_timeouts": eng.status()["ln_exchange_timeouts"],

@@ -194,12 +194,26 @@ int plb_comm_info(const PlbEngine* e, int32_t* rank, int32_t* world, int32_t* rc
  * plb_status / plb_status_ex: SYNCHRONISES the device and returns the count since its previous report; a non-zero report also re-zeroes
  *   the exchange buffer and the word (a producer's store that landed after its consumer gave up would otherwise look
  *   fresh to the next launch), so the step after a reported failure starts clean. 0 in every run so far.
+ * DATA-PARALLEL RUNS: the word is agreed between the ranks inside every plb_loss_fwd_bwd[_dual] call of an engine with a
+ *   communicator — one float per rank, summed by a one-element all-reduce issued after the last launch that can raise
+ *   it (overlap on: on the communication stream, between the head piece and the first weight's; overlap off: in
+ *   `stream`) and merged by the call's last launch. A time-out on ONE rank therefore gives EVERY rank a NaN loss, a
+ *   skipped update and a non-zero count (the sum over the ranks): the replicas stay bit-identical, nobody applies the
+ *   poisoned sum. The status all-reduce is not counted by plb_comm_pieces. A host that exchanges gradients by other
+ *   means uses plb_status_export / plb_status_import (below) at the same point. plb_loss_fwd (validation) issues no
+ *   collective: a word raised there is sticky and travels with the next training call.
  * No reference counterpart (the reference's LayerNorm is torch's kernel); the Python host raises HandoffTimeout. */
 int plb_status(PlbEngine* e, int32_t* ln_exchange_timeouts);
 /* plb_status + the number of plb_adamw_step calls the device left out since the word was raised (a host that counts
  * optimizer steps for the bias correction rewinds its count by it); either pointer may be NULL. */
 int plb_status_ex(PlbEngine* e, int32_t* ln_exchange_timeouts, int32_t* skipped_updates);
 int plb_poll_status(const PlbEngine* e, int32_t* ln_exchange_timeouts);
+/* For a host that runs the gradient exchange itself (torch.distributed, a foreign communicator): plb_status_export writes
+ * this rank's count as one float to `out` (device) behind the loss call in `stream`; the host sums it over the ranks;
+ * plb_status_import merges the sum into the word, mirrors it to the host and turns the last loss call's loss into NaN —
+ * before plb_adamw_step. (With the engine's own communicator both happen inside plb_loss_fwd_bwd.) */
+int plb_status_export(PlbEngine* e, float* out, void* stream);
+int plb_status_import(PlbEngine* e, const float* summed, void* stream);
 /* What the last training step exchanged: the number of collectives it issued (8 pieces for the reference's phoneme-only
  * step with overlap on, 1 with overlap off; one more after a dual-head step) and the floats they covered. The reference
  * has no counterpart (DDP's bucket count is internal to torch, train.py:218-221); a caller logs it to see which form of
@@ -265,11 +279,26 @@ int plb_profile_read(double* ms, int64_t* launches, double* flops, double* bytes
  *                                 the call must fail ("gradient exchange covered ..."), tests/test_gpu_comm_fake_rccl.py
  *   plb_debug_ln_fault(mode, n)   the next n fused LayerNorm launches run with a broken hand-off (1: one column tile
  *                                 never publishes; 2: consumed granules stay tagged), tests/test_gpu_handoff_fault.py
+ *   plb_debug_hb_audit(e, on, k)  happens-before audit of the backward's three streams: a host-side
+ *                                 vector-clock model of every event record / stream wait the engine issues, checked
+ *                                 against the cross-stream buffer accesses of each launch; a violation fails the loss
+ *                                 call. k >= 0: the MODEL forgets the k-th wait of the next call (the audit must then
+ *                                 report it; the HIP call is still made). Also PLBERT_HB_AUDIT=1. plb_debug_hb_report
+ *                                 returns the checks made, the violations and the first one's text.
+ *   plb_comm_trace / plb_comm_trace_read
+ *                                 timing events around every all-reduce piece of the last loss call: when the piece was
+ *                                 released, when its collective had finished, begin / end of the weight-gradient tail
+ *                                 (bench.py --gpus N prints them: RCCL-vs-GEMM contention readable from one line)
  *   plb_set_gemm_nt_tile / plb_set_gemm_nt_prefetch / plb_set_attn_bwd_fused
  *                                 force a tile, a K-loop form or the attention-backward form for the launches that
  *                                 follow (0 / -1 / 0 restore the per-shape policy), tests/test_gpu_kernels.py, tools/ */
 void plb_debug_skip_piece(int index);
 void plb_debug_ln_fault(int mode, int launches);
+int plb_debug_hb_audit(PlbEngine* e, int32_t on, int32_t break_wait);
+int plb_debug_hb_report(const PlbEngine* e, int64_t* checks, int32_t* violations, char* first, int32_t first_bytes);
+int plb_comm_trace(PlbEngine* e, int32_t on);
+int plb_comm_trace_read(PlbEngine* e, int32_t max_pieces, int32_t* n, int64_t* begin, int64_t* end, float* released_ms,
+                        float* done_ms, float* tail_ms);
 void plb_set_gemm_nt_tile(int tile);
 void plb_set_gemm_nt_prefetch(int on);
 void plb_set_attn_bwd_fused(int on);

@@ -160,13 +160,19 @@ def ragged_batch(B, S, lengths, seed, vocab_hi=185):
     return labels, masked, list(lengths), idxs
 
 
-def capture_model(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, full, n_steps, lr=7e-5):
-    """Run reference forward / loss / backward / AdamW and store what the tests compare."""
+def capture_model(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, full, n_steps, lr=7e-5, init="deterministic"):
+    """Run reference forward / loss / backward / AdamW and store what the tests compare.
+
+    ``init`` names the weight generator both sides regenerate from ``seed``: "deterministic" (every tensor noisy, so
+    bias paths are exercised) or "reference" (``plbert_amd.reference_init_state_dict`` = the reference's own
+    initialisation, train.py:263-270 — what ``PLBertTrainer`` and therefore ``bench.py`` start from)."""
     pcfg = plbert_amd.AlbertConfig(**cfg_kwargs)
-    sd = plbert_amd.deterministic_state_dict(pcfg, num_phonemes, num_tokens, seed=seed)
+    gen = plbert_amd.deterministic_state_dict if init == "deterministic" else plbert_amd.reference_init_state_dict
+    sd = gen(pcfg, num_phonemes, num_tokens, seed=seed)
     labels, masked, lengths, idxs = batch
     out = dict(labels=labels, masked=masked, lengths=np.array(lengths), index=obj_array(idxs),
-               seed=np.array(seed), num_phonemes=np.array(num_phonemes), num_tokens=np.array(num_tokens),
+               seed=np.array(seed), init=np.array(init), lr=np.array(lr),
+               num_phonemes=np.array(num_phonemes), num_tokens=np.array(num_tokens),
                cfg_keys=np.array(list(cfg_kwargs.keys())), cfg_vals=np.array(list(cfg_kwargs.values())))
 
     m = build_reference(cfg_kwargs, num_phonemes, num_tokens, sd)
@@ -293,12 +299,26 @@ def capture_dualloss(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, n_s
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "dualloss" / "large": regenerate only those fixtures
+    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "dualloss" / "large" / "fullsize_a" / "fullsize_d": only those
+    real = dict(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                max_position_embeddings=512, num_hidden_layers=12)
     # (4) BASELINE configs[3]'s architecture (hidden 1024, 24 shared layers, 16 heads, FFN 4096; SURVEY.md section 8:
     # ALBERT-large's heads / FFN width) at 4 x 256 = 1024 tokens with one ragged row: the token count at which the
     # engine runs its fused LayerNorm epilogues with FOUR column tiles per row block (H = 1024); probes only
     large = dict(vocab_size=188, hidden_size=1024, num_attention_heads=16, intermediate_size=4096,
                  max_position_embeddings=512, num_hidden_layers=24)
+    # (5) the sizes BASELINE.json configs[1] / configs[3] state, on EXACTLY bench.py's rank-0 inputs: reference
+    # initialisation seed 0 (PLBertTrainer's default), synthetic_batch(B, 512, seed=1234), AdamW lr 7e-5 — probes only
+    # (loss, 16 logit rows, per-parameter gradient norms + probes, AdamW loss trajectory). The reference's step on these
+    # batches is 30-70 s of CPU; they are captured on request only ("fullsize_a" / "fullsize_d"), not in the default run.
+    if only == "fullsize_a":
+        capture_model("real_s512_b32", real, 188, 0, plbert_amd.synthetic_batch(32, 512, seed=1234), seed=0,
+                      full=False, n_steps=5, init="reference")
+        return
+    if only == "fullsize_d":
+        capture_model("real_h1024_s512_b16", large, 188, 0, plbert_amd.synthetic_batch(16, 512, seed=1234), seed=0,
+                      full=False, n_steps=2, init="reference")
+        return
     if only in ("", "large"):
         capture_model("real_h1024_s256_b4", large, 188, 0, ragged_batch(4, 256, [256, 256, 256, 201], seed=8), seed=24,
                       full=False, n_steps=2)
@@ -331,8 +351,6 @@ def main():
     capture_model("small_h128_multitask", small, 188, 96, ragged_batch(3, 40, [40, 33, 7], seed=4), seed=22,
                   full=True, n_steps=0)
     # (3) the real 768/12 model (configs/config.yml:32-39); weights regenerated on both sides, not stored
-    real = dict(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
-                max_position_embeddings=512, num_hidden_layers=12)
     lab, msk, lens, idx = plbert_amd.synthetic_batch(8, 128, seed=1234)
     capture_model("real_s128_b8", real, 188, 0, (lab, msk, lens, idx), seed=23, full=False, n_steps=5)
     capture_model("real_s512_b2_ragged", real, 188, 0, ragged_batch(2, 512, [512, 300], seed=6), seed=23,

@@ -54,10 +54,11 @@ PUBLIC_SYMBOLS = [
     "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
     "plb_sync_weights", "plb_forward", "plb_pooler", "plb_loss_fwd_bwd", "plb_loss_fwd", "plb_loss_fwd_bwd_dual", "plb_adamw_step",
     "plb_set_fp8", "plb_fp8_state", "plb_token_head_steps", "plb_set_token_head_steps", "plb_comm_unique_id", "plb_comm_init", "plb_comm_destroy",
-    "plb_comm_info", "plb_comm_pieces", "plb_status", "plb_status_ex", "plb_poll_status", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
+    "plb_comm_info", "plb_comm_pieces", "plb_status", "plb_status_ex", "plb_poll_status", "plb_status_export", "plb_status_import", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
     "plb_mask_batch", "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
     # test / tuning hooks (documented as such at the end of the header)
-    "plb_debug_skip_piece", "plb_debug_ln_fault", "plb_set_gemm_nt_tile", "plb_set_gemm_nt_prefetch", "plb_set_attn_bwd_fused",
+    "plb_debug_skip_piece", "plb_debug_ln_fault", "plb_debug_hb_audit", "plb_debug_hb_report", "plb_comm_trace", "plb_comm_trace_read",
+    "plb_set_gemm_nt_tile", "plb_set_gemm_nt_prefetch", "plb_set_attn_bwd_fused",
 ]
 
 
@@ -195,6 +196,18 @@ def lib():
     L.plb_status_ex.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.plb_poll_status.restype = C.c_int
     L.plb_poll_status.argtypes = [vp, C.POINTER(i32)]
+    L.plb_status_export.restype = C.c_int
+    L.plb_status_export.argtypes = [vp, vp, vp]
+    L.plb_status_import.restype = C.c_int
+    L.plb_status_import.argtypes = [vp, vp, vp]
+    L.plb_debug_hb_audit.restype = C.c_int
+    L.plb_debug_hb_audit.argtypes = [vp, i32, i32]
+    L.plb_debug_hb_report.restype = C.c_int
+    L.plb_debug_hb_report.argtypes = [vp, i64p, C.POINTER(i32), C.c_char_p, i32]
+    L.plb_comm_trace.restype = C.c_int
+    L.plb_comm_trace.argtypes = [vp, i32]
+    L.plb_comm_trace_read.restype = C.c_int
+    L.plb_comm_trace_read.argtypes = [vp, i32, C.POINTER(i32), i64p, i64p, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)]
     L.plb_debug_ln_fault.restype = None
     L.plb_debug_ln_fault.argtypes = [C.c_int, C.c_int]
     L.plb_debug_skip_piece.restype = None

@@ -16,7 +16,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <array>
+#include <map>
 #include <new>
+#include <string>
 
 #include "../../include/plbert.h"
 #include "plbert_kernels.h"
@@ -146,6 +149,59 @@ struct Carve {  // bump allocator over the workspace, 256-B aligned regions
   }
 };
 
+// ---- happens-before audit of the backward's three streams (debug: PLBERT_HB_AUDIT=1 / plb_debug_hb_audit) --------------
+// A host-side MODEL of the ordering the engine asks HIP for, kept beside the real calls: every stream carries a vector
+// clock; an event record snapshots the recording stream's clock, a stream wait merges the snapshot into the waiter's.
+// Every access to a buffer that more than one stream touches in a loss call (a flat gradient range, the partial-row
+// tables, the scratch / slab areas, ...) is logged as (byte range, stream, that stream's tick, read or write), and is
+// checked on entry against every logged access of ANOTHER stream to overlapping bytes where at least one of the two
+// writes: the earlier one must be inside the later stream's clock, i.e. ordered before it by a record / wait chain.
+// It reasons about the calls the engine makes, not about timing: a missing hipStreamWaitEvent is reported on every
+// run, not once in eighty. DESIGN.md section 4 carries the table this checks.
+struct HbAudit {
+  enum { MAIN = 0, SIDE = 1, COMM = 2, NS = 3 };
+  typedef std::array<uint64_t, NS> VC;
+  struct Acc { const char* what; uintptr_t a, b; int st; uint64_t tick; bool wr; };
+  bool on = false;
+  int break_wait = -1;     // test hook: the MODEL forgets its n-th wait of the next loss call (the HIP call is still made)
+  int waits = 0;
+  VC vc[NS] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  std::map<hipEvent_t, VC> ev;
+  std::vector<Acc> log;
+  int64_t checks = 0;
+  int violations = 0;
+  std::string first;
+  static const char* name(int st) { return st == MAIN ? "main" : st == SIDE ? "side" : "comm"; }
+  void record(hipEvent_t e, int st) { vc[st][st] += 1; ev[e] = vc[st]; }
+  void wait(int st, hipEvent_t e) {
+    const int n = waits++;
+    if (n == break_wait) { break_wait = -1; return; }
+    auto it = ev.find(e);
+    if (it == ev.end()) return;   // never recorded: HIP treats the wait as a no-op, so does the model
+    for (int i = 0; i < NS; ++i) if (it->second[i] > vc[st][i]) vc[st][i] = it->second[i];
+  }
+  void access(int st, const void* p, size_t bytes, bool wr, const char* what) {
+    if (!p || !bytes) return;
+    const uintptr_t a = (uintptr_t)p, b = a + bytes;
+    vc[st][st] += 1;
+    for (const Acc& x : log) {
+      if (x.st == st || !(wr || x.wr) || x.b <= a || b <= x.a) continue;
+      ++checks;
+      if (x.tick > vc[st][x.st]) {
+        if (!violations++) {
+          char m[384];
+          snprintf(m, sizeof(m), "%s of '%s' on the %s stream is not ordered after the %s of '%s' on the %s stream", wr ? "write" : "read",
+                   what, name(st), x.wr ? "write" : "read", x.what, name(x.st));
+          first = m;
+        }
+      }
+    }
+    log.push_back(Acc{what, a, b, st, vc[st][st], wr});
+  }
+  // Everything logged so far is ordered before the main stream's present: start the next call with an empty log.
+  void new_call() { log.clear(); waits = 0; }
+};
+
 }  // namespace
 
 struct PlbEngine {
@@ -211,6 +267,18 @@ struct PlbEngine {
   bool grads_reduced = false;   // the gradients of the last loss call have been all-reduced
   int64_t piece_floats = 0;     // floats submitted as pieces by the current loss call (must add up to the gradient range)
   int32_t piece_count = 0;      // collectives the last step issued (pieces by the loss call + in-stream all-reduces)
+  // the step's health word travels too (one float, summed over the ranks): every rank skips, or none
+  hipEvent_t ev_status = nullptr;
+  bool status_pending = false;  // the word's all-reduce is in flight on the communication stream
+  int32_t status_collectives = 0;
+  float* last_loss = nullptr;   // where the last loss call put its loss (plb_status_import turns it into NaN)
+  HbAudit hb;
+  // exchange trace (plb_comm_trace): timing events around every piece of the last loss call
+  struct PieceTrace { int64_t a, b; hipEvent_t released, done; };
+  bool trace_on = false;
+  std::vector<PieceTrace> trace;
+  std::vector<hipEvent_t> trace_pool;
+  hipEvent_t tr_call0 = nullptr, tr_tail0 = nullptr, tr_tail1 = nullptr;
   // bound buffers
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
   char* ws = nullptr;
@@ -259,6 +327,18 @@ static bool tn_fill_chip() {
   static const bool v = [] { const char* e = getenv("PLBERT_TN_SPLITS"); return !(e && !strcmp(e, "xcd")); }();
   return v;
 }
+// PLBERT_TN_CUS = n (64..256, default 256): workgroups a big weight-gradient GEMM may occupy. The tail of the backward is
+// where the gradient pieces travel; RCCL's kernels need CUs of their own and the one-workgroup-per-CU grids leave 4-16
+// (dense.weight: 4). Lowering n trades GEMM width for CUs the collective finds free — a knob for the first real N > 1 run
+// (bench.py reports the tail's GEMM time with and without the exchange), read once per process.
+static int tn_cus() {
+  static const int v = [] {
+    const char* e = getenv("PLBERT_TN_CUS");
+    const int n = e ? atoi(e) : 256;
+    return (n >= 64 && n <= 256) ? n : 256;
+  }();
+  return v;
+}
 static int tn_splits(int64_t Mtot, int N, int K, int* rows_per_split) {
   const bool big = tn_big(Mtot, N, K);
   const int tiles = big ? (N / 256) * (K / 256) : ((N + 127) / 128) * ((K + 127) / 128);
@@ -270,7 +350,7 @@ static int tn_splits(int64_t Mtot, int N, int K, int* rows_per_split) {
     // contiguous range of token rows through its L2 (a split may straddle two XCDs).
     int s = 32 / tiles;
     if (s < 1) s = 1;
-    splits = tiles >= 256 ? 1 : (tn_fill_chip() ? 256 / tiles : 8 * s);  // a wide output (token head) needs no row splits
+    splits = tiles >= 256 ? 1 : (tn_fill_chip() ? (tn_cus() / tiles > 0 ? tn_cus() / tiles : 1) : 8 * s);  // a wide output (token head) needs no row splits
   }
   const int64_t maxs = Mtot / 64;
   if (splits > maxs) splits = (int)maxs;
@@ -319,6 +399,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   e->part_rows = e->ln_blocks > (int)(2 * Tp / 128) ? e->ln_blocks : (int)(2 * Tp / 128);
   if (const char* v = getenv("PLBERT_GELU_STASH")) e->gelu_dstash_on = strcmp(v, "u") != 0;
   if (const char* v = getenv("PLBERT_FP8_TN")) e->fp8_tn = strcmp(v, "0") != 0;
+  if (const char* v = getenv("PLBERT_HB_AUDIT")) e->hb.on = strcmp(v, "0") != 0;
   Carve cv;
   // bf16 weight copies: the flat copy (+ slack so 128-row B tiles never leave the buffer) and transposes
   e->o_wbf = cv.take((e->ptotal + 256 * (H > I ? H : I)) * 2);
@@ -448,6 +529,9 @@ extern "C" void plb_destroy(PlbEngine* e) {
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->side) (void)hipStreamDestroy(e->side);
   if (e->host_err) (void)hipHostFree(e->host_err);
+  for (auto& t : e->trace) { (void)hipEventDestroy(t.released); (void)hipEventDestroy(t.done); }
+  for (auto ev : e->trace_pool) (void)hipEventDestroy(ev);
+  for (auto ev : {e->tr_call0, e->tr_tail0, e->tr_tail1}) if (ev) (void)hipEventDestroy(ev);
   delete e;
 }
 
@@ -508,6 +592,26 @@ extern "C" int plb_bind(PlbEngine* e, float* params, float* grads, float* exp_av
     hipError_t e_ = (x);                                                                            \
     if (e_ != hipSuccess) return fail("%s: %s at %s:%d", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
+
+// Stream-ordering calls of the engine go through these two: the HIP call, and — audit on — the same step in the model.
+static int hb_idx(const PlbEngine* e, hipStream_t s) {
+  if (e->side && s == e->side) return HbAudit::SIDE;
+  if (e->comm_stream && s == e->comm_stream) return HbAudit::COMM;
+  return HbAudit::MAIN;
+}
+static hipError_t ev_record(PlbEngine* e, hipEvent_t ev, hipStream_t s) {
+  const hipError_t r = hipEventRecord(ev, s);
+  if (e->hb.on) e->hb.record(ev, hb_idx(e, s));
+  return r;
+}
+static hipError_t ev_wait(PlbEngine* e, hipStream_t s, hipEvent_t ev) {
+  const hipError_t r = hipStreamWaitEvent(s, ev, 0);
+  if (e->hb.on) e->hb.wait(hb_idx(e, s), ev);
+  return r;
+}
+// a launch (or memset / collective) enqueued on `stream` reads / writes these bytes
+#define HB_R(stream, ptr, bytes, what) do { if (e->hb.on) e->hb.access(hb_idx(e, stream), (ptr), (size_t)(bytes), false, what); } while (0)
+#define HB_W(stream, ptr, bytes, what) do { if (e->hb.on) e->hb.access(hb_idx(e, stream), (ptr), (size_t)(bytes), true, what); } while (0)
 
 // ---- fp8 mode ---------------------------------------------------------------------------------------------------------
 // Sites: activations X (layer input), A (attention block output), G (gelu output) in e4m3; gradients DP (dpre2) and DU
@@ -863,7 +967,7 @@ extern "C" int plb_forward(PlbEngine* e, const int64_t* ids, const int32_t* leng
     TRY(fp8_update_scales(e, s));
     e->fp8_ready = true;
   }
-  TRY(plb_launch_step_status(e->at<unsigned int>(e->o_lnerr), nullptr, e->host_err_dev, s));
+  TRY(plb_launch_step_status(e->at<unsigned int>(e->o_lnerr), nullptr, e->host_err_dev, nullptr, s));
   return 0;
 }
 
@@ -926,6 +1030,12 @@ static int backward_tail(PlbEngine* e, const int64_t* masked_ids, bf16_t* dy, in
 static int g_debug_skip_piece = -1;   // test hook (plb_debug_skip_piece): drop the n-th piece of a loss call
 extern "C" void plb_debug_skip_piece(int index) { g_debug_skip_piece = index; }
 
+static hipEvent_t trace_event(PlbEngine* e) {
+  if (!e->trace_pool.empty()) { hipEvent_t v = e->trace_pool.back(); e->trace_pool.pop_back(); return v; }
+  hipEvent_t v = nullptr;
+  (void)hipEventCreate(&v);   // timing enabled
+  return v;
+}
 static int reduce_piece(PlbEngine* e, int64_t a, int64_t b, hipStream_t after) {
   if (!e->comm || b <= a) return 0;
   if (g_debug_skip_piece >= 0 && e->piece_count == g_debug_skip_piece) {  // what a forgotten tensor looks like
@@ -933,10 +1043,20 @@ static int reduce_piece(PlbEngine* e, int64_t a, int64_t b, hipStream_t after) {
     e->piece_count += 1;
     return 0;
   }
-  HIPTRY(hipEventRecord(e->ev_piece, after));
-  HIPTRY(hipStreamWaitEvent(e->comm_stream, e->ev_piece, 0));
+  PlbEngine::PieceTrace tr{a, b, nullptr, nullptr};
+  if (e->trace_on) {
+    tr.released = trace_event(e); tr.done = trace_event(e);
+    (void)hipEventRecord(tr.released, after);
+  }
+  HIPTRY(ev_record(e, e->ev_piece, after));
+  HIPTRY(ev_wait(e, e->comm_stream, e->ev_piece));
+  HB_W(e->comm_stream, e->grads + a, (b - a) * 4, "all-reduce piece (in place)");
   const int rc = g_rccl.AllReduce(e->grads + a, e->grads + a, (size_t)(b - a), kNcclFloat32, kNcclSum, e->comm, e->comm_stream);
   if (rc != kNcclSuccess) return fail("ncclAllReduce: %s", g_rccl.GetErrorString(rc));
+  if (e->trace_on) {
+    (void)hipEventRecord(tr.done, e->comm_stream);
+    e->trace.push_back(tr);
+  }
   e->comm_pending = true;
   e->piece_floats += b - a;
   e->piece_count += 1;
@@ -945,14 +1065,56 @@ static int reduce_piece(PlbEngine* e, int64_t a, int64_t b, hipStream_t after) {
 static bool overlapping(const PlbEngine* e) { return e->comm && e->overlap; }
 // Close the pieces issued so far: later joins wait on ev_comm_done.
 static int pieces_done(PlbEngine* e) {
+  if (e->hb.on && e->hb.violations)
+    return fail("happens-before audit: %d violation(s), first: %s", e->hb.violations, e->hb.first.c_str());
   if (!e->comm_pending) return 0;
   // the pieces are disjoint by construction; together they must be exactly the range AdamW is about to consume (a
   // one-rank communicator would not show a forgotten tensor: its all-reduce is the identity)
   const int64_t want = e->ptrain + (e->tok_grads_live ? e->ptotal - e->poff[PLB_TOK_W] : 0);
   if (e->piece_floats != want)
     return fail("gradient exchange covered %lld of %lld floats", (long long)e->piece_floats, (long long)want);
-  HIPTRY(hipEventRecord(e->ev_comm_done, e->comm_stream));
+  HIPTRY(ev_record(e, e->ev_comm_done, e->comm_stream));
   e->grads_reduced = true;
+  return 0;
+}
+
+// ---- the step's health word, agreed between the ranks -----------------------------------------------------------
+// A fused LayerNorm hand-off that times out (never observed) raises the error word of THE RANK IT HAPPENED ON; that
+// rank's gradients are invalid — and have been summed into every replica by the time AdamW runs. So the word travels
+// too: one float per rank (its count), summed over the communicator inside the loss call, after the last launch that
+// can raise it (the layer loop; the tail has no hand-offs) and before the call's status launch. Every rank then sees a
+// non-zero word, returns a NaN loss, skips the update (and every later one, until plb_status has reported) and raises
+// from its next status poll: replicas stay bit-identical. Overlapped form: on the communication stream, between the head
+// piece and the first weight's (it is long done when the tail's last GEMM ends; the main stream joins it before the
+// status launch); serial form: in the caller's stream. The SAME position in the collective sequence on every rank,
+// including a rank that takes the zero-loss path.
+static float* status_float(const PlbEngine* e) { return e->at<float>(e->o_lnerr) + 16; }
+static int status_exchange(PlbEngine* e, hipStream_t s) {
+  if (!e->comm) return 0;
+  float* f = status_float(e);
+  TRY(plb_launch_status_export(e->at<unsigned int>(e->o_lnerr), f, s));
+  hipStream_t cs = overlapping(e) ? e->comm_stream : s;
+  if (cs != s) {
+    HIPTRY(ev_record(e, e->ev_piece, s));
+    HIPTRY(ev_wait(e, cs, e->ev_piece));
+  }
+  const int rc = g_rccl.AllReduce(f, f, 1, kNcclFloat32, kNcclSum, e->comm, cs);
+  if (rc != kNcclSuccess) return fail("ncclAllReduce (status word): %s", g_rccl.GetErrorString(rc));
+  if (cs != s) {
+    HIPTRY(ev_record(e, e->ev_status, cs));
+    e->status_pending = true;
+  }
+  e->status_collectives += 1;
+  return 0;
+}
+// last launch of a loss call: merge the ranks' word (if it travelled), NaN loss + host mirror when it is set
+static int status_finish(PlbEngine* e, float* loss, hipStream_t s) {
+  if (e->status_pending) {
+    HIPTRY(ev_wait(e, s, e->ev_status));
+    e->status_pending = false;
+  }
+  e->last_loss = loss;
+  TRY(plb_launch_step_status(e->at<unsigned int>(e->o_lnerr), loss, e->host_err_dev, e->comm ? status_float(e) : nullptr, s));
   return 0;
 }
 
@@ -977,12 +1139,27 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     // All-reduce pieces of a PREVIOUS backward that nobody joined (two plb_loss_fwd_bwd calls with no plb_allreduce_grads /
     // plb_adamw_step between them: gradient probing, a caller that skips a step on a bad loss) still read and write the
     // gradient buffer on the communication stream: this call's kernels must not touch it before they have finished.
-    if (e->comm && e->comm_pending) HIPTRY(hipStreamWaitEvent(s, e->ev_comm_done, 0));
+    if (e->comm && e->comm_pending) HIPTRY(ev_wait(e, s, e->ev_comm_done));
     e->tok_grads_live = token_targets != nullptr;
     e->comm_pending = false;
     e->grads_reduced = false;
     e->piece_floats = 0;
     e->piece_count = 0;
+    e->status_collectives = 0;
+    if (e->hb.on) {
+      // this call's first launches on the caller's stream may touch any byte of the workspace and the gradient buffer:
+      // whatever the previous call left running on the side / communication stream must be ordered before them
+      HB_W(s, e->ws, e->ws_bytes, "start of a loss call (whole workspace)");
+      HB_W(s, e->grads, e->ptotal * 4, "start of a loss call (gradient buffer)");
+      if (e->hb.violations) return fail("happens-before audit: %s", e->hb.first.c_str());
+      e->hb.new_call();
+    }
+    for (auto& t : e->trace) { e->trace_pool.push_back(t.released); e->trace_pool.push_back(t.done); }
+    e->trace.clear();
+    if (e->trace_on) {
+      if (!e->tr_call0) { (void)hipEventCreate(&e->tr_call0); (void)hipEventCreate(&e->tr_tail0); (void)hipEventCreate(&e->tr_tail1); }
+      (void)hipEventRecord(e->tr_call0, s);
+    }
   }
   if (n_masked == 0 && !token_targets) {  // train.py:129 — zero loss, nothing to back-propagate
     HIPTRY(hipMemsetAsync(loss, 0, sizeof(float), s));
@@ -996,10 +1173,16 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
         const int64_t ranges[8][2] = {{o[PLB_HEAD_W], e->ptrain}, {o[PLB_Q_W], o[PLB_Q_B]}, {o[PLB_FFN_W], o[PLB_FFN_B]},
                                       {o[PLB_FFNO_W], o[PLB_FFNO_B]}, {0, o[PLB_Q_W]}, {o[PLB_Q_B], o[PLB_FFN_W]},
                                       {o[PLB_FFN_B], o[PLB_FFNO_W]}, {o[PLB_FFNO_B], o[PLB_HEAD_W]}};
-        for (auto& r : ranges)
-          if (reduce_piece(e, r[0], r[1], s)) return 1;
+        for (int i = 0; i < 8; ++i) {
+          HB_W(s, e->grads + ranges[i][0], (ranges[i][1] - ranges[i][0]) * 4, "zero gradients of a rank without masked phonemes");
+          if (reduce_piece(e, ranges[i][0], ranges[i][1], s)) return 1;
+          if (i == 0 && status_exchange(e, s)) return 1;   // where a regular step issues it: behind the head piece
+        }
         if (pieces_done(e)) return 1;
+      } else if (status_exchange(e, s)) {
+        return 1;
       }
+      if (status_finish(e, loss, s)) return 1;
     }
     return 0;
   }
@@ -1045,6 +1228,7 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       HIPTRY(hipMemsetAsync(e->grd(PLB_HEAD_W), 0, (size_t)(e->psize[PLB_HEAD_W] + e->psize[PLB_HEAD_B]) * 4, s));
   }
   // the phoneme head's gradients are final: their all-reduce runs beside the whole backward
+  if (backward) HB_W(s, e->grd(PLB_HEAD_W), (e->ptrain - e->poff[PLB_HEAD_W]) * 4, "phoneme head gradients (weight-gradient GEMM, bias column sums)");
   if (backward && overlapping(e) && reduce_piece(e, e->poff[PLB_HEAD_W], e->ptrain, s)) return 1;
   if (loss_parts) HIPTRY(hipMemcpyAsync(loss_parts, loss, sizeof(float), hipMemcpyDeviceToDevice, s));
 
@@ -1088,6 +1272,7 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       float* gw = NTp == NT ? e->grd(PLB_TOK_W) : e->at<float>(e->o_tgrad);
       if (weight_grad(e, tdl, NTp, NTp, xL, H, Tp, NTp, H, gw, s)) return 1;
       if (NTp != NT) HIPTRY(hipMemcpyAsync(e->grd(PLB_TOK_W), gw, (size_t)NT * H * 4, hipMemcpyDeviceToDevice, s));
+      HB_W(s, e->grd(PLB_TOK_W), (e->ptotal - e->poff[PLB_TOK_W]) * 4, "token head gradients");
       if (overlapping(e) && reduce_piece(e, e->poff[PLB_TOK_W], e->ptotal, s)) return 1;
       // dH += dlogits · Wt, on top of the scattered phoneme-head rows (in place: a tile reads its residual
       // before its own stores)
@@ -1102,7 +1287,10 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       TRY(fp8_update_scales(e, s));
       e->fp8_ready = true;
     }
-    TRY(plb_launch_step_status(e->at<unsigned int>(e->o_lnerr), loss, e->host_err_dev, s));
+    // (no collective in a loss-only call: ranks may validate different numbers of batches. A word raised here is sticky
+    // and travels with the next training call's exchange.)
+    e->last_loss = loss;
+    TRY(plb_launch_step_status(e->at<unsigned int>(e->o_lnerr), loss, e->host_err_dev, nullptr, s));
     return 0;
   }
 
@@ -1229,6 +1417,8 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     }
     bf16_t* tmp = dy; dy = dy_other; dy_other = tmp;
   }
+  // the last launch that can raise the hand-off error word is behind us: the word travels now (beside the tail)
+  if (status_exchange(e, s)) return 1;
   if (backward_tail(e, masked_ids, dy, B, S, du_rows, s)) return 1;
   if (e->fp8_on) {
     // This call's maxima become the next call's scales; a calibration call arms the fp8 path. AFTER the tail: the weight-
@@ -1238,10 +1428,9 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     e->fp8_ready = true;
     e->fp8_bwd_ready = true;
   }
-  // Last launch of the step: a hand-off of the fused LayerNorm launches that timed out turns the loss into NaN and shows
-  // in plb_poll_status; plb_adamw_step skips on the same word. Nothing waits for anything.
-  TRY(plb_launch_step_status(e->at<unsigned int>(e->o_lnerr), loss, e->host_err_dev, s));
-  return 0;
+  // Last launch of the step: a hand-off of the fused LayerNorm launches that timed out — on ANY rank — turns the loss into
+  // NaN and shows in plb_poll_status; plb_adamw_step skips on the same word. No host round trip anywhere.
+  return status_finish(e, loss, s);
 }
 
 // Tail of the backward on two streams.
@@ -1260,14 +1449,23 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   const int64_t Mtot = (int64_t)L * Tp;
   PlbGemmNT g;
   // side stream -------------------------------------------------------------------------------------------------------
+  // (HB_R / HB_W: the happens-before audit's view of each launch — what it reads that another stream wrote, what it
+  // writes that another stream reads. The stash operands of the GEMMs are only ever written in the layer loop, which the
+  // fork orders before both streams: they are covered by the whole-workspace entry at the fork.)
   bf16_t* evec = e->at<bf16_t>(e->o_e);
   bf16_t* de = e->at<bf16_t>(e->o_de);
   memset(&g, 0, sizeof(g));
   g.A = dy; g.lda = H; g.B = e->at<bf16_t>(e->o_winT); g.ldb = H; g.M = (int)Tp; g.N = E; g.K = H; g.Mstore = (int)Tp;
   g.C = de; g.ldc = E;
+  HB_R(s2, dy, Tp * H * 2, "dX of application 0"); HB_W(s2, de, Tp * E * 2, "dE (map-in backward)");
   TRY(plb_launch_gemm_nt(&g, 0, 0, s2));
+  HB_W(s2, e->at<float>(s2 != s ? e->o_slab2 : e->o_slab), (s2 != s ? e->slab2_floats : e->slab_floats) * 4, "map-in weight-gradient slab");
+  HB_W(s2, e->grd(PLB_MAP_W), e->psize[PLB_MAP_W] * 4, "map-in weight gradient");
   if (weight_grad(e, dy, H, H, evec, E, Tp, H, E, e->grd(PLB_MAP_W), s2, s2 != s)) return 1;
+  HB_W(s2, scratch2, 512 * (3 * H > I ? 3 * H : I) * 4, "column-sum scratch of the side stream");
+  HB_W(s2, e->grd(PLB_MAP_B), H * 4, "map-in bias gradient");
   TRY(plb_launch_colsum(dy, 1, (size_t)Tp, H, H, e->grd(PLB_MAP_B), H, 0, scratch2, 128, s2));
+  HB_W(s2, e->grd(PLB_TYPE_EMB), e->psize[PLB_TYPE_EMB] * 4, "token-type embedding gradient");
   HIPTRY(hipMemsetAsync(e->grd(PLB_TYPE_EMB), 0, (size_t)e->psize[PLB_TYPE_EMB] * 4, s2));
   PlbEmbed em;
   memset(&em, 0, sizeof(em));
@@ -1277,6 +1475,8 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   em.dout = de; em.lddo = E; em.dword = e->grd(PLB_WORD_EMB); em.dpos = e->grd(PLB_POS_EMB);
   em.dx = e->at<float>(e->o_dxe);
   em.partials = e->at<float>(e->o_parte); em.nblocks = e->emb_blocks;
+  HB_W(s2, em.dx, Tp * E * 4, "embedding LayerNorm backward rows"); HB_W(s2, em.partials, (int64_t)e->emb_blocks * 2 * E * 4, "embedding LayerNorm partials");
+  HB_W(s2, e->grd(PLB_WORD_EMB), (e->poff[PLB_MAP_W] - e->poff[PLB_WORD_EMB]) * 4, "embedding tables' and embedding LayerNorm's gradients");
   TRY(plb_launch_embed_bwd(&em, s2));
   TRY(plb_launch_embed_scatter(&em, e->P, s2));
   TRY(plb_launch_colsum(em.partials, 0, (size_t)e->emb_blocks, 2 * E, 2 * E, e->grd(PLB_EMB_LN_W), 2 * E, 0, scratch2, 1, s2));
@@ -1284,42 +1484,57 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   TRY(plb_launch_colsum(e->grd(PLB_POS_EMB), 0, (size_t)e->P, E, E, e->grd(PLB_TYPE_EMB), E, 0, scratch2, 1, s2));
   // Q/K/V biases: the attention-backward kernels left the column sums of every 32-row patch they stored, per application
   // ([L][B*QT*4][3H])
+  HB_R(s2, e->at<float>(e->o_qkvcol), (int64_t)L * (B * ((S + 127) / 128) * 4) * 3 * H * 4, "Q/K/V bias partial rows");
+  HB_W(s2, e->grd(PLB_Q_B), 3 * H * 4, "Q/K/V bias gradients");
   TRY(plb_launch_colsum(e->at<float>(e->o_qkvcol), 0, (size_t)L * (size_t)(B * ((S + 127) / 128) * 4), 3 * H, 3 * H, e->grd(PLB_Q_B),
                         3 * H, 0, scratch2, 64, s2));
-  if (du_rows > 0)
+  HB_W(s2, e->grd(PLB_FFN_B), I * 4, "ffn.bias gradient");
+  if (du_rows > 0) {
+    HB_R(s2, e->at<float>(e->o_ducol), (int64_t)L * du_rows * I * 4, "dU column-sum partial rows");
     TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 16, s2));
-  else
+  } else {
+    HB_R(s2, e->at<bf16_t>(e->o_du), Mtot * I * 2, "dU of every application");
     TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 64, s2));
+  }
   // LayerNorm-backward partials [L*blocks][3H]: dgamma | dbeta | column sums of dx. (Summing the L applications into
   // one image inside the kernel — PlbLayerNorm.accumulate — was measured: the read-modify-write costs the main stream
   // 2.5 us per launch to save side-stream traffic that is hidden behind the weight-gradient GEMMs anyway.) The third block is the bias
   // gradient of the Linear that produced the LayerNorm's input (dense.bias = colsum(dpre1), ffn_output.bias =
   // colsum(dpre2)): no pass over the stacked gradients.
   const size_t prow = (size_t)L * e->part_rows_used;
+  HB_R(s2, e->at<float>(e->o_part1), (int64_t)L * e->part_rows * 3 * H * 4, "LayerNorm-1 backward partial rows");
+  HB_W(s2, e->grd(PLB_DENSE_B), 3 * H * 4, "dense.bias + LayerNorm-1 affine gradients");
   TRY(plb_launch_colsum(e->at<float>(e->o_part1), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN1_W), 2 * H, 0, scratch2, 64, s2));
   TRY(plb_launch_copy_cols(scratch2, 64, 3 * H, 2 * H, H, e->grd(PLB_DENSE_B), s2));
+  HB_R(s2, e->at<float>(e->o_part2), (int64_t)L * e->part_rows * 3 * H * 4, "LayerNorm-2 backward partial rows");
+  HB_W(s2, e->grd(PLB_LN2_W), 2 * H * 4, "LayerNorm-2 affine gradients"); HB_W(s2, e->grd(PLB_FFNO_B), H * 4, "ffn_output.bias gradient");
   TRY(plb_launch_colsum(e->at<float>(e->o_part2), 0, prow, 3 * H, 3 * H, e->grd(PLB_LN2_W), 2 * H, 0, scratch2, 64, s2));
   TRY(plb_launch_copy_cols(scratch2, 64, 3 * H, 2 * H, H, e->grd(PLB_FFNO_B), s2));
-  if (s2 != s) HIPTRY(hipEventRecord(e->ev_join, s2));
+  if (s2 != s) HIPTRY(ev_record(e, e->ev_join, s2));
   // main stream: shared-layer weight gradients, one token-major GEMM per weight over all L applications ------------
   // Overlapped exchange: a weight's range travels as soon as its GEMM (+ slab reduction) has written it. The small
   // tensors between the weights in the flat order (biases, LayerNorm, embeddings) come from the side stream, which needs
   // about as long as the first three GEMMs: they go last, behind the join, so the main stream never waits for it early.
   const bool ov = overlapping(e);
   const bool t8 = e->tn8_call;   // fp8 call: gradient (e5m2) x activation (e4m3) images of all L applications
+  float* const slab = e->at<float>(e->o_slab);
+  HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_Q_W), 3 * H * H * 4, "Q/K/V weight gradients");
   if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dq8), e->at<uint8_t>(e->o_x8), Mtot, 3 * H, H, F8_DQ, F8_X, e->grd(PLB_Q_W), s)
          : weight_grad(e, e->at<bf16_t>(e->o_dqkv), 3 * H, 3 * H, e->at<bf16_t>(e->o_x), H, Mtot, 3 * H, H, e->grd(PLB_Q_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_Q_W], e->poff[PLB_Q_B], s)) return 1;
+  HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_FFN_W), (int64_t)I * H * 4, "ffn.weight gradient");
   if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_du8), e->at<uint8_t>(e->o_a8), Mtot, I, H, F8_DU, F8_A, e->grd(PLB_FFN_W), s)
          : weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_FFN_W], e->poff[PLB_FFN_B], s)) return 1;
+  HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_FFNO_W), (int64_t)I * H * 4, "ffn_output.weight gradient");
   if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp8), e->at<uint8_t>(e->o_g8), Mtot, H, I, F8_DP, F8_G, e->grd(PLB_FFNO_W), s)
          : weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_FFNO_W], e->poff[PLB_FFNO_B], s)) return 1;
+  HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_DENSE_W), (int64_t)H * H * 4, "dense.weight gradient");
   if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp18), e->at<uint8_t>(e->o_c8), Mtot, H, H, F8_DP1, F8_C, e->grd(PLB_DENSE_W), s)
          : weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
   if (ov) {
-    if (s2 != s) HIPTRY(hipStreamWaitEvent(s, e->ev_join, 0));
+    if (s2 != s) HIPTRY(ev_wait(e, s, e->ev_join));
     if (reduce_piece(e, 0, e->poff[PLB_Q_W], s)) return 1;                    // embeddings, map-in, LN2
     if (reduce_piece(e, e->poff[PLB_Q_B], e->poff[PLB_FFN_W], s)) return 1;  // QKV biases, dense (the smallest weight), LN1
     if (reduce_piece(e, e->poff[PLB_FFN_B], e->poff[PLB_FFNO_W], s)) return 1;
@@ -1331,21 +1546,27 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
 static int backward_tail(PlbEngine* e, const int64_t* masked_ids, bf16_t* dy, int B, int S, int du_rows, hipStream_t s) {
   hipStream_t s2 = s;
   float* scratch2 = e->at<float>(e->o_scratch);
+  // the layer loop (all of it on the caller's stream) has written the stash, the partial-row tables, dX: one entry
+  HB_W(s, e->ws, e->ws_bytes, "layer loop (whole workspace)");
+  if (e->trace_on) (void)hipEventRecord(e->tr_tail0, s);
   if (e->side) {
     s2 = e->side;
     scratch2 = e->at<float>(e->o_scratch2);
-    HIPTRY(hipEventRecord(e->ev_fork, s));
-    HIPTRY(hipStreamWaitEvent(s2, e->ev_fork, 0));
+    HIPTRY(ev_record(e, e->ev_fork, s));
+    HIPTRY(ev_wait(e, s2, e->ev_fork));
   }
   const int rc = backward_tail_streams(e, masked_ids, dy, B, S, du_rows, s, s2, scratch2);
   // Whatever happened above, the caller's stream must not run ahead of the side stream's work (also on an error
   // path: the side stream may hold launches that read buffers the caller is about to reuse).
   if (s2 != s) {
-    if (rc) (void)hipEventRecord(e->ev_join, s2);
-    const hipError_t je = hipStreamWaitEvent(s, e->ev_join, 0);
+    if (rc) (void)ev_record(e, e->ev_join, s2);
+    const hipError_t je = ev_wait(e, s, e->ev_join);
     if (!rc && je != hipSuccess) return fail("plb_loss_fwd_bwd: joining the side stream: %s", hipGetErrorString(je));
   }
+  if (e->trace_on) (void)hipEventRecord(e->tr_tail1, s);
   if (rc) return rc;
+  // from here on the caller's stream may again touch anything in the workspace (the next call's forward will)
+  HB_W(s, e->ws, e->ws_bytes, "after the side stream's join (whole workspace)");
   return pieces_done(e);
 }
 
@@ -1391,6 +1612,8 @@ extern "C" int plb_comm_destroy(PlbEngine* e) {
   e->comm = nullptr; e->comm_rank = 0; e->comm_world = 1; e->comm_pending = false;
   if (e->ev_piece) { (void)hipEventDestroy(e->ev_piece); e->ev_piece = nullptr; }
   if (e->ev_comm_done) { (void)hipEventDestroy(e->ev_comm_done); e->ev_comm_done = nullptr; }
+  if (e->ev_status) { (void)hipEventDestroy(e->ev_status); e->ev_status = nullptr; }
+  e->status_pending = false;
   if (e->comm_stream) { (void)hipStreamDestroy(e->comm_stream); e->comm_stream = nullptr; }
   return 0;
 }
@@ -1407,6 +1630,7 @@ extern "C" int plb_comm_init(PlbEngine* e, const uint8_t id[PLB_COMM_ID_BYTES], 
   HIPTRY(hipStreamCreateWithPriority(&e->comm_stream, hipStreamNonBlocking, hi));
   HIPTRY(hipEventCreateWithFlags(&e->ev_piece, kStreamOrderEvent));
   HIPTRY(hipEventCreateWithFlags(&e->ev_comm_done, kStreamOrderEvent));
+  HIPTRY(hipEventCreateWithFlags(&e->ev_status, kStreamOrderEvent));
   RcclId u;
   memcpy(&u, id, sizeof(u));
   const int rc = g_rccl.CommInitRank(&e->comm, world, u, rank);
@@ -1433,12 +1657,14 @@ extern "C" int plb_comm_info(const PlbEngine* e, int32_t* rank, int32_t* world, 
 
 extern "C" int plb_status_ex(PlbEngine* e, int32_t* ln_exchange_timeouts, int32_t* skipped_updates) {
   if (!e || !e->ws) return fail("plb_status: engine not bound");
-  unsigned int v[2] = {0, 0};
+  unsigned int v[3] = {0, 0, 0};
   HIPTRY(hipDeviceSynchronize());
   HIPTRY(hipMemcpy(v, e->at<unsigned int>(e->o_lnerr), sizeof(v), hipMemcpyDeviceToHost));
   if (ln_exchange_timeouts) *ln_exchange_timeouts = (int32_t)v[0];
   if (skipped_updates) *skipped_updates = (int32_t)v[1];
   if (v[0]) {
+    // the token head counts its own AdamW steps on the host (tok_steps): take back the ones the device left out (word 2)
+    e->tok_steps = e->tok_steps > (int)v[2] ? e->tok_steps - (int)v[2] : 0;
     // Reported once, then gone: a producer whose store landed after its consumer had given up leaves a tagged granule
     // that the next launch would take for a fresh one, so the exchange buffer is zeroed again (the device is idle
     // here) together with the error word and its host mirror. The next step starts clean.
@@ -1454,6 +1680,64 @@ extern "C" int plb_status(PlbEngine* e, int32_t* ln_exchange_timeouts) { return 
 extern "C" int plb_poll_status(const PlbEngine* e, int32_t* ln_exchange_timeouts) {
   if (!e || !e->ws || !e->host_err) return fail("plb_poll_status: engine not bound");
   if (ln_exchange_timeouts) *ln_exchange_timeouts = (int32_t)*(volatile const unsigned int*)e->host_err;
+  return 0;
+}
+
+// A host that exchanges the gradients ITSELF (torch.distributed fallback, a foreign communicator) must let the health word
+// travel with them: export after the loss call, sum the float over the ranks, import before plb_adamw_step.
+extern "C" int plb_status_export(PlbEngine* e, float* out, void* stream) {
+  if (!e || !e->ws || !out) return fail("plb_status_export: bad argument");
+  TRY(plb_launch_status_export(e->at<unsigned int>(e->o_lnerr), out, (hipStream_t)stream));
+  return 0;
+}
+extern "C" int plb_status_import(PlbEngine* e, const float* summed, void* stream) {
+  if (!e || !e->ws || !summed) return fail("plb_status_import: bad argument");
+  TRY(plb_launch_step_status(e->at<unsigned int>(e->o_lnerr), e->last_loss, e->host_err_dev, summed, (hipStream_t)stream));
+  return 0;
+}
+
+// ---- debug: happens-before audit, exchange trace -------------------------------------------------------------------------
+extern "C" int plb_debug_hb_audit(PlbEngine* e, int32_t on, int32_t break_wait) {
+  if (!e) return fail("plb_debug_hb_audit: null engine");
+  e->hb = HbAudit();
+  e->hb.on = on != 0;
+  e->hb.break_wait = break_wait;
+  return 0;
+}
+extern "C" int plb_debug_hb_report(const PlbEngine* e, int64_t* checks, int32_t* violations, char* first, int32_t first_bytes) {
+  if (!e) return fail("plb_debug_hb_report: null engine");
+  if (checks) *checks = e->hb.checks;
+  if (violations) *violations = e->hb.violations;
+  if (first && first_bytes > 0) snprintf(first, (size_t)first_bytes, "%s", e->hb.first.c_str());
+  return 0;
+}
+extern "C" int plb_comm_trace(PlbEngine* e, int32_t on) {
+  if (!e) return fail("plb_comm_trace: null engine");
+  e->trace_on = on != 0;
+  return 0;
+}
+// Timing of the last loss call's pieces, in milliseconds since the call's first launch: when the piece was released (the
+// launch that completed its range had finished) and when its all-reduce had finished; tail_ms[2] = begin / end of the tail
+// of weight-gradient GEMMs on the caller's stream. Synchronises on the events. Returns the number of pieces in *n.
+extern "C" int plb_comm_trace_read(PlbEngine* e, int32_t max_pieces, int32_t* n, int64_t* begin, int64_t* end, float* released_ms,
+                                   float* done_ms, float* tail_ms) {
+  if (!e || !n) return fail("plb_comm_trace_read: bad argument");
+  *n = 0;
+  if (!e->tr_call0) return 0;
+  if (tail_ms) {
+    HIPTRY(hipEventSynchronize(e->tr_tail1));
+    HIPTRY(hipEventElapsedTime(&tail_ms[0], e->tr_call0, e->tr_tail0));
+    HIPTRY(hipEventElapsedTime(&tail_ms[1], e->tr_call0, e->tr_tail1));
+  }
+  for (auto& t : e->trace) {
+    if (*n >= max_pieces) break;
+    HIPTRY(hipEventSynchronize(t.done));
+    if (begin) begin[*n] = t.a;
+    if (end) end[*n] = t.b;
+    if (released_ms) HIPTRY(hipEventElapsedTime(&released_ms[*n], e->tr_call0, t.released));
+    if (done_ms) HIPTRY(hipEventElapsedTime(&done_ms[*n], e->tr_call0, t.done));
+    *n += 1;
+  }
   return 0;
 }
 
@@ -1485,11 +1769,12 @@ extern "C" int plb_allreduce_grads(PlbEngine* e, void* stream) {
   if (!e->grads) return fail("plb_allreduce_grads: no gradient buffer bound");
   hipStream_t s = (hipStream_t)stream;
   if (e->comm_pending) {  // the loss call issued the pieces: join them
-    HIPTRY(hipStreamWaitEvent(s, e->ev_comm_done, 0));
+    HIPTRY(ev_wait(e, s, e->ev_comm_done));
     e->comm_pending = false;
     return 0;
   }
   if (e->grads_reduced) return 0;
+  HB_W(s, e->grads, e->ptotal * 4, "in-stream all-reduce of the gradient buffer");
   int rc = g_rccl.AllReduce(e->grads, e->grads, (size_t)e->ptrain, kNcclFloat32, kNcclSum, e->comm, s);
   e->piece_count = 1;
   e->piece_floats = e->ptrain;
@@ -1555,9 +1840,10 @@ extern "C" int plb_adamw_step(PlbEngine* e, double lr, double beta1, double beta
   if (step < 1) return fail("plb_adamw_step: step counts from 1");
   hipStream_t s = (hipStream_t)stream;
   if (e->comm_pending) {  // all-reduce pieces still in flight on the communication stream
-    HIPTRY(hipStreamWaitEvent(s, e->ev_comm_done, 0));
+    HIPTRY(ev_wait(e, s, e->ev_comm_done));
     e->comm_pending = false;
   }
+  HB_R(s, e->grads, e->ptotal * 4, "AdamW (reads the gradient buffer)");
   TRY(plb_launch_adamw(e->params, e->grads, e->m, e->v, e->at<bf16_t>(e->o_wbf), (size_t)e->ptrain, lr, beta1, beta2, eps,
                        weight_decay, step, grad_scale, e->at<unsigned int>(e->o_lnerr), 1, s));
   if (e->tok_grads_live) {
@@ -1567,7 +1853,7 @@ extern "C" int plb_adamw_step(PlbEngine* e, double lr, double beta1, double beta
     e->tok_steps += 1;
     TRY(plb_launch_adamw(e->params + o, e->grads + o, e->m + o, e->v + o, e->at<bf16_t>(e->o_wbf) + o,
                          (size_t)(e->ptotal - o), lr, beta1, beta2, eps, weight_decay, e->tok_steps, grad_scale,
-                         e->at<unsigned int>(e->o_lnerr), 0, s));
+                         e->at<unsigned int>(e->o_lnerr), 2, s));
   }
   return sync_transposes(e, s, false);   // fp8 copies: delayed scaling from here on (the weights moved by one AdamW step)
 }

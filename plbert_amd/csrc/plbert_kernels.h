@@ -254,13 +254,15 @@ int plb_launch_apply_mask(const PlbApplyMask* p, hipStream_t stream);
 // AdamW (torch.optim.AdamW semantics) over a flat range; also refreshes the bf16 compute copy.
 // skip_if_nonzero (two device words, or null): the launch leaves everything untouched when word 0 is non-zero — the engine's
 // hand-off error word, so that a step whose LayerNorm statistics are invalid never reaches the parameters (no host round
-// trip); with count_skip the launch then adds 1 to word 1 (optimizer steps left out)
+// trip); with count_skip = 1 / 2 the launch then adds 1 to that word (optimizer steps left out: trainable range / token head)
 int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf16_t* p_bf16, size_t n, double lr, double beta1,
                      double beta2, double eps, double wd, int step, double grad_scale, unsigned int* skip_if_nonzero,
                      int count_skip, hipStream_t stream);
 // End of a loss call: mirror the hand-off error word into host-visible memory (host_mirror: device pointer of a pinned
 // host word) and, when it is non-zero, overwrite the loss with NaN — whoever reads the loss sees that the step is invalid
-int plb_launch_step_status(const unsigned int* ln_err, float* loss, unsigned int* host_mirror, hipStream_t stream);
+int plb_launch_step_status(unsigned int* ln_err, float* loss, unsigned int* host_mirror, const float* summed, hipStream_t stream);
+// *out = the word as a float (the ranks' words are summed by an all-reduce; step_status merges the sum back)
+int plb_launch_status_export(const unsigned int* ln_err, float* out, hipStream_t stream);
 int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream);
 // dst[c, r] = bf16(src[r, c]) for r<R, c<C ; dst has ldd >= R columns (zero fill is the caller's job)
 int plb_launch_transpose_cast(const float* src, int R, int C, bf16_t* dst, int ldd, hipStream_t stream);

@@ -834,8 +834,9 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* x, int n, fl
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* pb, size_t n,
                                                     float decay, float omb1, float b2, float omb2, float eps, float step,
                                                     float bc2_sqrt, float gscale, unsigned int* skip, int count_skip) {
-  if (skip && *skip) {   // skip[1] counts the optimizer steps left out (the host rewinds its step count by it)
-    if (count_skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + 1, 1u);
+  if (skip && *skip) {   // skip[count_skip] counts the optimizer steps left out (1: the trainable range — the host rewinds
+    // its step count by it; 2: the token head, which keeps a step count of its own)
+    if (count_skip && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(skip + count_skip, 1u);
     return;
   }
   const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -856,9 +857,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
   *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
   if (pb) { uint2 o; o.x = pack_bf2(pp[0], pp[1]); o.y = pack_bf2(pp[2], pp[3]); *(uint2*)(pb + i) = o; }
 }
-// one thread, at the end of a loss call (plb_launch_step_status)
-__global__ void step_status_kernel(const unsigned int* ln_err, float* loss, unsigned int* host_mirror) {
+// one thread, after the last launch of a loss call that can raise the word: this rank's count as a float, for the sum
+// over the ranks (plb_launch_status_export)
+__global__ void status_export_kernel(const unsigned int* ln_err, float* out) {
   const unsigned int e = *ln_err;
+  *out = (float)(e < (1u << 20) ? e : (1u << 20));
+}
+// one thread, at the end of a loss call (plb_launch_step_status). summed: the ranks' counts after their all-reduce (or
+// null): a word another rank raised becomes this rank's too — every replica skips the update, or none does
+__global__ void step_status_kernel(unsigned int* ln_err, float* loss, unsigned int* host_mirror, const float* summed) {
+  unsigned int e = *ln_err;
+  if (summed) {
+    const float f = *summed;
+    if (f > 0.5f) {
+      const unsigned int g = f < 1048576.f ? (unsigned int)(f + 0.5f) : (1u << 20);
+      if (g > e) { e = g; *ln_err = e; }
+    }
+  }
   if (host_mirror) __hip_atomic_store(host_mirror, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (e && loss) *loss = __builtin_nanf("");
 }
@@ -1188,8 +1203,13 @@ extern "C" int plb_launch_adamw(float* p, const float* g, float* m, float* v, bf
                      (float)(lr / bc1), (float)sqrt(bc2), (float)grad_scale, skip_if_nonzero, count_skip);
   return LAUNCH_OK();
 }
-extern "C" int plb_launch_step_status(const unsigned int* ln_err, float* loss, unsigned int* host_mirror, hipStream_t stream) {
-  hipLaunchKernelGGL(step_status_kernel, dim3(1), dim3(1), 0, stream, ln_err, loss, host_mirror);
+extern "C" int plb_launch_step_status(unsigned int* ln_err, float* loss, unsigned int* host_mirror, const float* summed,
+                                      hipStream_t stream) {
+  hipLaunchKernelGGL(step_status_kernel, dim3(1), dim3(1), 0, stream, ln_err, loss, host_mirror, summed);
+  return LAUNCH_OK();
+}
+extern "C" int plb_launch_status_export(const unsigned int* ln_err, float* out, hipStream_t stream) {
+  hipLaunchKernelGGL(status_export_kernel, dim3(1), dim3(1), 0, stream, ln_err, out);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_cast_bf16(const float* src, bf16_t* dst, size_t n, hipStream_t stream) {

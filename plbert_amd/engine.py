@@ -216,6 +216,43 @@ class HipEngine:
                 fn(err)
             raise err
 
+    def status_exchange(self, all_reduce):
+        """For a host-side gradient exchange (torch.distributed fallback): let the step's health word travel with the
+        gradients — export this rank's count, ``all_reduce(tensor)`` sums it over the ranks in place, import merges the
+        sum (every rank then skips the update, returns a NaN loss and raises HandoffTimeout, or none does). With the
+        engine's own communicator the same happens inside plb_loss_fwd_bwd."""
+        if not hasattr(self, "_status_f"):
+            self._status_f = torch.zeros(1, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.plb_status_export(self.handle, self._status_f.data_ptr(), self._stream()), "plb_status_export")
+            all_reduce(self._status_f)
+            _lib.check(self.L.plb_status_import(self.handle, self._status_f.data_ptr(), self._stream()), "plb_status_import")
+
+    def hb_audit(self, on=True, break_wait=-1):
+        """Debug: happens-before audit of the backward's streams (include/plbert.h: plb_debug_hb_audit)."""
+        _lib.check(self.L.plb_debug_hb_audit(self.handle, int(bool(on)), int(break_wait)), "plb_debug_hb_audit")
+
+    def hb_report(self):
+        n, v = C.c_int64(), C.c_int32()
+        buf = C.create_string_buffer(512)
+        _lib.check(self.L.plb_debug_hb_report(self.handle, C.byref(n), C.byref(v), buf, 512), "plb_debug_hb_report")
+        return {"checks": int(n.value), "violations": int(v.value), "first": buf.value.decode()}
+
+    def comm_trace(self, on=True):
+        _lib.check(self.L.plb_comm_trace(self.handle, int(bool(on))), "plb_comm_trace")
+
+    def comm_trace_read(self, max_pieces=16):
+        """Per piece of the last loss call: (begin, end) float range, release and completion time in ms since the call's
+        first launch; plus (begin, end) of the weight-gradient tail. Synchronises on the trace events."""
+        n = C.c_int32()
+        a, b = (C.c_int64 * max_pieces)(), (C.c_int64 * max_pieces)()
+        r, d, t = (C.c_float * max_pieces)(), (C.c_float * max_pieces)(), (C.c_float * 2)()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.plb_comm_trace_read(self.handle, max_pieces, C.byref(n), a, b, r, d, t), "plb_comm_trace_read")
+        return {"tail_ms": [round(t[0], 4), round(t[1], 4)],
+                "pieces": [{"range": [int(a[i]), int(b[i])], "released_ms": round(r[i], 4), "done_ms": round(d[i], 4)}
+                           for i in range(n.value)]}
+
     def comm_pieces(self):
         """(collectives, floats) of the last step's gradient exchange."""
         n, f = C.c_int32(), C.c_int64()

@@ -59,7 +59,7 @@ class DeviceFeeder:
     pinned buffers, device slots and copy stream persist."""
 
     def __init__(self, loader, device=None, depth=2, vocab_size=None, validate=True, word_separator=None, prefetch=4,
-                 draw_budget=None):
+                 draw_budget=None, mask_on_copy_stream=True):
         self.loader = loader
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.depth = max(2, int(depth))
@@ -71,6 +71,12 @@ class DeviceFeeder:
         self._ready = [torch.cuda.Event() for _ in range(self.depth)]
         self._free = [torch.cuda.Event() for _ in range(self.depth)]
         self._prev = None
+        # decision records: plb_apply_mask runs on the COPY stream right behind the upload (one batch ahead of the step that
+        # reads it), and the masked count comes back through a pinned word on that stream — the step's stream never waits
+        # for the host and the host never waits for the step (on the compute stream the count's read-back is queued behind
+        # the previous step: the host then cannot enqueue a step before the one before it has finished)
+        self.mask_on_copy_stream = bool(mask_on_copy_stream)
+        self._outs = [None] * self.depth            # per slot: device outputs of plb_apply_mask + pinned count
         self._limited = draw_budget is not None
         self._budget = threading.Semaphore(int(draw_budget or 0))
 
@@ -209,13 +215,17 @@ class DeviceFeeder:
                     kind, buf, meta, info = item
                     k = i % self.depth
                     i += 1
-                    pending.append((k, kind, meta, info, self._upload(k, buf)))
+                    dev = self._upload(k, buf)
+                    if kind == "decisions" and self.mask_on_copy_stream:
+                        self._apply_mask(k, meta, info, dev, self.copy_stream)
+                    pending.append((k, kind, meta, info, dev))
                 if not pending:
                     break
                 if self._prev is not None:
                     self.release(self._prev)
                 k, kind, meta, info, dev = pending.pop(0)
                 torch.cuda.current_stream(self.device).wait_event(self._ready[k])
+                info["_slot"] = k
                 batch = self._stage(kind, meta, info, dev)
                 batch._slot = k
                 self._prev = batch
@@ -230,26 +240,58 @@ class DeviceFeeder:
                                self._view(dev, meta, "offsets"), self._view(dev, meta, "flat"), info["n_masked"],
                                int(sum(lengths)), tok)
         # decisions: the masking is applied on the device (plb_apply_mask)
+        k = info["_slot"]
+        if not self.mask_on_copy_stream:
+            self._apply_mask(k, meta, info, dev, torch.cuda.current_stream(self.device))
+        o = self._outs[k]
+        o["done"].synchronize()                     # the masked count has landed in the pinned word (copy stream: long ago)
+        n = int(o["n_host"][0])                     # the one host read of the path: the masked count sizes the loss GEMM
+        v = lambda name: o[name][: B * S].view(B, S)
+        lens_t = None if all(x == S for x in lengths) else o["lens"][:B]
+        return StagedBatch(v("masked"), v("labels"), lens_t, o["offsets"][: B + 1], o["flat"][:n], n, int(sum(lengths)),
+                           v("tokens") if "word_token" in meta else None)
+
+    def _apply_mask(self, k, meta, info, dev, stream):
+        """plb_apply_mask of slot k's decision records on ``stream`` (behind the upload), outputs into the slot's own
+        device buffers (kept for the feeder's lifetime; grown under the copy stream's allocator pool), the masked count
+        copied into a pinned word; ``_ready[k]`` / ``done`` re-recorded behind it."""
         import ctypes as C
         from . import _lib
         from .symbols import MASK_ID
         L = _lib.lib()
+        B, S = info["B"], info["S"]
+        o = self._outs[k]
+        if o is None or o["cap"] < B * S or o["bcap"] < B:
+            cap, bcap = max(B * S, o["cap"] if o else 0), max(B, o["bcap"] if o else 0)
+            cur = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(self.copy_stream):
+                i64 = lambda n: torch.empty(n, dtype=torch.int64, device=self.device)
+                i32 = lambda n: torch.empty(n, dtype=torch.int32, device=self.device)
+                new = dict(cap=cap, bcap=bcap, labels=i64(cap), masked=i64(cap), tokens=i64(cap), lens=i32(bcap),
+                           offsets=i32(bcap + 1), flat=i32(cap), scratch=i32(bcap + cap),
+                           n_host=torch.zeros(1, dtype=torch.int32).pin_memory(), done=torch.cuda.Event())
+            for t in new.values():
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(cur)
+            if o is not None:
+                for t in o.values():
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(cur)        # a step still reading the old buffers keeps them until it is done
+            o = self._outs[k] = new
         v = lambda n: self._view(dev, meta, n)
         wtok = v("word_token") if "word_token" in meta else None
-        labels = torch.empty((B, S), dtype=torch.int64, device=self.device)
-        masked = torch.empty_like(labels)
-        tokens = torch.empty_like(labels) if wtok is not None else None
-        lens = torch.empty(B, dtype=torch.int32, device=self.device)
-        offsets = torch.empty(B + 1, dtype=torch.int32, device=self.device)
-        flat = torch.empty(B * S, dtype=torch.int32, device=self.device)
-        scratch = torch.empty(B + B * S, dtype=torch.int32, device=self.device)
         p = lambda t: None if t is None else t.data_ptr()
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(L.plb_apply_mask(v("ids").data_ptr(), v("sample_off").data_ptr(), v("word_off").data_ptr(),
-                                    v("word_begin").data_ptr(), v("word_len").data_ptr(), v("action").data_ptr(),
-                                    v("repl").data_ptr(), p(wtok), int(self.word_separator or 0), v("crop_start").data_ptr(),
-                                    B, S, MASK_ID, labels.data_ptr(), masked.data_ptr(), p(tokens), lens.data_ptr(),
-                                    offsets.data_ptr(), flat.data_ptr(), scratch.data_ptr(), stream), "plb_apply_mask")
-        n = int(offsets[B].item())                  # the one host read of the path: the masked count sizes the loss GEMM
-        lens_t = None if all(x == S for x in lengths) else lens
-        return StagedBatch(masked, labels, lens_t, offsets, flat[:n], n, int(sum(lengths)), tokens)
+        with torch.cuda.stream(stream):
+            if stream is not self.copy_stream:
+                stream.wait_event(self._ready[k])
+            _lib.check(L.plb_apply_mask(v("ids").data_ptr(), v("sample_off").data_ptr(), v("word_off").data_ptr(),
+                                        v("word_begin").data_ptr(), v("word_len").data_ptr(), v("action").data_ptr(),
+                                        v("repl").data_ptr(), p(wtok), int(self.word_separator or 0), v("crop_start").data_ptr(),
+                                        B, S, MASK_ID, o["labels"].data_ptr(), o["masked"].data_ptr(),
+                                        o["tokens"].data_ptr() if wtok is not None else None, o["lens"].data_ptr(),
+                                        o["offsets"].data_ptr(), o["flat"].data_ptr(), o["scratch"].data_ptr(),
+                                        C.c_void_p(stream.cuda_stream)), "plb_apply_mask")
+            o["n_host"].copy_(o["offsets"][B:B + 1], non_blocking=True)
+            o["done"].record(stream)
+            if stream is self.copy_stream:
+                self._ready[k].record(stream)

@@ -194,12 +194,32 @@ def _batches(loader, trainer, device_masking, word_separator, budget=None):
         yield trainer.stage_batch(lab, msk, lens, idx)
 
 
+MAX_HANDOFF_RETRIES = 3
+
+
+def _checked(trainer, call, note=None):
+    """``float(call().item())`` with the engine's hand-off status checked right behind the read-back, where it is exact. A
+    step the engine declared invalid (HandoffTimeout: NaN loss, update left out on every rank, engine reset — never
+    observed) is run again, up to MAX_HANDOFF_RETRIES times; in a data-parallel run every rank sees the failure at
+    the same step (the health word is agreed inside the step), so all ranks retry the same batch together."""
+    from .engine import HandoffTimeout
+    for attempt in range(MAX_HANDOFF_RETRIES + 1):
+        try:
+            loss = float(call().item())
+            trainer.engine.raise_if_failed()
+            return loss
+        except HandoffTimeout as ex:
+            if attempt == MAX_HANDOFF_RETRIES:
+                raise
+            if note is not None:
+                note(handoff_timeout=str(ex), retry=attempt + 1)
+
+
 def validate(trainer, val_loader, device_masking=False, word_separator=None):
     """Mean of the per-batch losses, forward only (train.py:288-304; masks are re-drawn each pass, as there)."""
     total, n = 0.0, 0
     for b in _batches(val_loader, trainer, device_masking, word_separator):
-        total += float(trainer.engine.loss_fwd(b.masked, b.labels, b.lengths, b.offsets, b.flat, b.n_masked).item())
-        trainer.engine.raise_if_failed()
+        total += _checked(trainer, lambda: trainer.engine.loss_fwd(b.masked, b.labels, b.lengths, b.offsets, b.flat, b.n_masked))
         n += 1
     return total / max(n, 1)
 
@@ -226,8 +246,9 @@ def train_loop(trainer, train_loader, val_loader, current_step, num_steps, save_
     while epoch < max_epochs:
         epoch += 1
         for batch in _batches(train_loader, trainer, device_masking, word_separator, 0):
-            loss = float(trainer.step(batch).item())            # the reference syncs here too (loss.item(), train.py:395)
-            trainer.engine.raise_if_failed()                     # the step has completed: its hand-off status is exact here
+            # the reference syncs here too (loss.item(), train.py:395); the step has completed, so its hand-off status
+            # is exact: a step the engine declared invalid is run again (_checked)
+            loss = _checked(trainer, lambda: trainer.step(batch), lambda **kw: log(step=current_step, epoch=epoch, **kw))
             current_step += 1
             window.append(loss)
             rec = {"phoneme_loss": loss, "epoch": epoch, "step": current_step}

@@ -153,9 +153,17 @@ class PLBertTrainer:
         if dual:
             a, b = self.engine.token_range
             self.reducer.all_reduce_(self.engine.grads[a:b])
+        if self.reducer.active:  # the health word travels with the gradients: every rank skips a poisoned update, or none
+            self.engine.status_exchange(self.reducer.all_reduce_)
 
     def step(self, batch: StagedBatch):
-        """zero_grad + backward + optimizer.step of train.py:355-357; returns the local loss (device)."""
+        """zero_grad + backward + optimizer.step of train.py:355-357; returns the local loss (device).
+        HandoffTimeout (never observed; engine.py) is raised by the engine call that follows the failed step's completion
+        on the device: the failed step's update has been left out on EVERY rank (the health word is agreed between the
+        ranks inside the step) and all replicas are bit-identical, so the caller may run the batch again. A loop that
+        reads each loss back (run.train_loop) sees it exactly at the failed step, on every rank at the same step; a
+        loop that does not may see it one step late and — in a data-parallel run — at different steps on different
+        ranks: such a caller must treat it as the end of the run (resume from the replicas, which are consistent)."""
         loss = self.loss_and_grads(batch)
         dual = batch.token_ids is not None
         if batch.n_masked == 0 and self.world == 1 and not dual:

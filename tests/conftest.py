@@ -26,7 +26,10 @@ def golden_cfg(g):
     kw = {k: int(v) for k, v in zip(g["cfg_keys"], g["cfg_vals"])}
     pcfg = plbert_amd.AlbertConfig(**kw)
     nph, ntok = int(g["num_phonemes"]), int(g["num_tokens"])
-    sd = plbert_amd.deterministic_state_dict(pcfg, nph, ntok, seed=int(g["seed"]))
+    # "init" names the generator the capture used (oracle/gen_golden.py: capture_model); fixtures older than it: deterministic
+    init = str(g["init"]) if "init" in g.files else "deterministic"
+    gen = plbert_amd.reference_init_state_dict if init == "reference" else plbert_amd.deterministic_state_dict
+    sd = gen(pcfg, nph, ntok, seed=int(g["seed"]))
     ocfg = Config(vocab_size=pcfg.vocab_size, embedding_size=pcfg.embedding_size, hidden_size=pcfg.hidden_size,
                   num_attention_heads=pcfg.num_attention_heads, intermediate_size=pcfg.intermediate_size,
                   num_hidden_layers=pcfg.num_hidden_layers, num_phonemes=nph, num_tokens=ntok)

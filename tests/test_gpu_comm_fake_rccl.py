@@ -78,9 +78,14 @@ def _worker(rank, world, port, lib, num_tokens, empty_rank, real, fp8, out):
             assert tr.engine.comm_info() == (rank, world, 29999)          # the stand-in, not a real RCCL
         if fp8:
             tr.engine.set_fp8(True)                                         # step 1 calibrates (bf16), steps 2-3 run on the images
+        # happens-before audit: every event record / stream wait of the steps below is mirrored in a
+        # vector-clock model and every cross-stream buffer access checked against it; a violation fails the loss call
+        tr.engine.hb_audit(True)
         b = tr.stage_batch(lab, msk, lens, ix, token_ids=tk)
         losses = [float(tr.step(b).item()) for _ in range(3)]
         torch.cuda.synchronize()
+        rep = tr.engine.hb_report()
+        assert rep["violations"] == 0 and rep["checks"] > (50 if mode == "rccl" else 10), rep
         assert tr.engine.status()["ln_exchange_timeouts"] == 0              # two processes share the GPU: hand-offs still arrive
         pieces = tr.engine.comm_pieces() if mode == "rccl" else None
         if fp8:
@@ -179,6 +184,126 @@ except RuntimeError as ex:
     print('CAUGHT')
 else:
     print('MISSED')
+"""
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert "CAUGHT" in r.stdout, r.stdout[-2000:]
+
+
+# ---- the step's health word at world 2 -----------------------------------------------------------------------------------
+def _fault_worker(rank, world, port, lib, out):
+    """A fused LayerNorm hand-off times out on RANK 1 ONLY (plb_debug_ln_fault, process-wide in that rank's process). Its
+    gradients are invalid and are summed into both replicas by the exchange: the word must travel with them, so that BOTH
+    ranks return a NaN loss, leave the update out, raise HandoffTimeout from their next call and — after the retry — end
+    bit-identical to an undisturbed run."""
+    import math
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PLBERT_RCCL_LIB=lib, FAKE_RCCL_TIMEOUT_S="60")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import plbert_amd
+    from plbert_amd import _lib
+    from plbert_amd.dist import shard_batch
+    from plbert_amd.engine import HandoffTimeout
+    from plbert_amd.train import PLBertTrainer
+
+    torch.cuda.set_device(0)
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                                  max_position_embeddings=512, num_hidden_layers=2)
+    lab, msk, lens, ix = shard_batch(plbert_amd.synthetic_batch(4, 512, seed=5), rank, world)
+    L = _lib.lib()
+    res = {}
+    for mode, overlap in (("rccl", True), ("rccl", False), ("torch", True)):
+        def make():
+            tr = PLBertTrainer(cfg, 188, max_batch=2, max_seq=512, lr=1e-3, seed=3, comm=mode, overlap=overlap)
+            return tr, tr.stage_batch(lab, msk, lens, ix)
+
+        def drop(tr):
+            if mode == "rccl":
+                tr.engine.comm_destroy()
+
+        tr, b = make()
+        clean = [float(tr.step(b).item()) for _ in range(3)]
+        torch.cuda.synchronize()
+        clean_params = tr.engine.params.clone()
+        drop(tr)
+        del tr
+        tr, b = make()
+        first = float(tr.step(b).item())
+        torch.cuda.synchronize()
+        p1 = tr.engine.params.clone()
+        if rank == 1:
+            L.plb_debug_ln_fault(1, 1)
+        try:
+            bad = tr.step(b)
+            torch.cuda.synchronize()
+        finally:
+            L.plb_debug_ln_fault(0, 0)
+        r = dict(nan=math.isnan(float(bad.item())), untouched=bool(torch.equal(tr.engine.params, p1)), raised=False, skipped=None)
+        try:
+            tr.step(b)
+        except HandoffTimeout as ex:
+            r.update(raised=True, skipped=ex.skipped_updates)
+        r["step_count"] = tr.step_count
+        rest = [float(tr.step(b).item()) for _ in range(2)]
+        torch.cuda.synchronize()
+        r.update(losses_match=[first] + rest == clean, equals_clean=bool(torch.equal(tr.engine.params, clean_params)),
+                 params=tr.engine.params.cpu().numpy().copy(), status=tr.engine.status())
+        res[(mode, overlap)] = r
+        drop(tr)
+        del tr
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_handoff_timeout_on_one_rank_is_every_ranks(fake_lib):
+    port = 29800 + ((os.getpid() + 700) % 1500)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_fault_worker, args=(2, port, fake_lib, out), nprocs=2, join=True)
+        res = dict(out)
+    for key in (("rccl", True), ("rccl", False), ("torch", True)):
+        for r in (0, 1):
+            v = res[r][key]
+            assert v["nan"], (key, r, "the failed step's loss must be NaN on every rank")
+            assert v["untouched"], (key, r, "no rank may apply the update built from the poisoned sum")
+            assert v["raised"] and v["skipped"] == 1 and v["step_count"] == 1, (key, r, v["raised"], v["skipped"], v["step_count"])
+            assert v["losses_match"] and v["equals_clean"], (key, r)
+            assert v["status"] == {"ln_exchange_timeouts": 0, "skipped_updates": 0}, (key, r, v["status"])
+        assert np.array_equal(res[0][key]["params"], res[1][key]["params"]), key
+
+
+@pytest.mark.parametrize("forgotten", [0, 2, 3, 6, 13])
+def test_the_audit_sees_a_forgotten_wait(fake_lib, forgotten):
+    """The happens-before audit must FIND a missing hipStreamWaitEvent: the model forgets the n-th wait of a step (the HIP call
+    is still made, so nothing races for real) — 0: the head piece behind the head's weight gradient, 2: the side stream
+    behind the layer loop, 3: the Q/K/V piece behind its weight-gradient GEMM, 6: the small pieces behind the side
+    stream's join, 13: AdamW behind the communication stream — and the step (13: the next one) must fail, naming it."""
+    code = f"""
+import os, sys
+sys.path.insert(0, {ROOT!r})
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='{29950 + (os.getpid() + forgotten) % 40}', PLBERT_RCCL_LIB={fake_lib!r})
+import torch, torch.distributed as dist
+import plbert_amd
+from plbert_amd.train import PLBertTrainer
+dist.init_process_group('gloo', rank=0, world_size=1)
+cfg = plbert_amd.AlbertConfig(vocab_size=188, embedding_size=64, hidden_size=256, num_attention_heads=4,
+                              intermediate_size=512, num_hidden_layers=2, max_position_embeddings=512)
+labels, masked, lens, idx = plbert_amd.synthetic_batch(2, 64, seed=3)
+tr = PLBertTrainer(cfg, 188, max_batch=2, max_seq=64, lr=1e-3, seed=1, force_collectives=True, comm='rccl', overlap=True)
+b = tr.stage_batch(labels, masked, lens, idx)
+tr.engine.hb_audit(True)
+tr.step(b); tr.step(b); torch.cuda.synchronize()
+rep = tr.engine.hb_report()
+assert rep['violations'] == 0 and rep['checks'] > 50, rep
+tr.engine.hb_audit(True, {forgotten})
+try:
+    tr.step(b); tr.step(b)
+except RuntimeError as ex:
+    assert 'happens-before audit' in str(ex), ex
+    print('CAUGHT', ex)
+else:
+    print('MISSED', tr.engine.hb_report())
 """
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert "CAUGHT" in r.stdout, r.stdout[-2000:]

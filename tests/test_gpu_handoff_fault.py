@@ -126,3 +126,42 @@ def test_process_batch_raises_too():
         step()
     assert opt.step_count == 1
     assert np.isfinite(float(step().item()))
+
+
+def test_dual_head_step_count_follows_the_skipped_updates():
+    """The token head keeps an AdamW step count of its own (plb_token_head_steps, torch keeps one per parameter): an update
+    the device left out must not advance it either, or the head's next update runs with the wrong bias correction."""
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                                  max_position_embeddings=512, num_hidden_layers=2)
+    labels, masked, lengths, idx = plbert_amd.synthetic_batch(2, 512, seed=5)
+    tok = np.random.RandomState(9).randint(0, 512, size=(2, 512)).astype(np.int64)
+
+    def make():
+        tr = plbert_amd.PLBertTrainer(cfg, 188, max_batch=2, max_seq=512, seed=3, lr=1e-3, num_tokens=512)
+        return tr, tr.stage_batch(labels, masked, lengths, idx, token_ids=tok)
+
+    tr, b = make()
+    ref = [float(tr.step(b).item()) for _ in range(3)]
+    torch.cuda.synchronize()
+    ref_params = tr.engine.params.clone()
+    assert tr.engine.token_head_steps == 3
+    del tr
+    tr, b = make()
+    L = _lib.lib()
+    assert float(tr.step(b).item()) == ref[0]
+    try:
+        L.plb_debug_ln_fault(1, 1)
+        bad = tr.step(b)
+        torch.cuda.synchronize()
+    finally:
+        L.plb_debug_ln_fault(0, 0)
+    assert math.isnan(float(bad.item()))
+    assert tr.engine.token_head_steps == 2                 # the host counted the launch it enqueued ...
+    with pytest.raises(HandoffTimeout):
+        tr.step(b)
+    assert tr.engine.token_head_steps == 1 and tr.step_count == 1   # ... and takes it back with the report
+    assert float(tr.step(b).item()) == ref[1]
+    assert float(tr.step(b).item()) == ref[2]
+    torch.cuda.synchronize()
+    assert tr.engine.token_head_steps == 3
+    assert torch.equal(tr.engine.params, ref_params)
