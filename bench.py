@@ -288,8 +288,11 @@ def pipeline_child(args):
     next(it)
     t0, n = time.perf_counter(), 0
     while time.perf_counter() - t0 < 3.0:
-        next(it)
-        n += 1
+        try:
+            next(it)
+            n += 1
+        except StopIteration:   # a fast producer finishes the epoch inside the window
+            it = iter(loader)
     producer = n * B / (time.perf_counter() - t0)
     del it
     cfg = plbert_amd.AlbertConfig(vocab_size=len(plbert_amd.symbols), hidden_size=768, num_attention_heads=12,

@@ -85,7 +85,9 @@ def _worker(rank, world, port, lib, num_tokens, empty_rank, real, fp8, out):
         losses = [float(tr.step(b).item()) for _ in range(3)]
         torch.cuda.synchronize()
         rep = tr.engine.hb_report()
-        assert rep["violations"] == 0 and rep["checks"] > (50 if mode == "rccl" else 10), rep
+        assert rep["violations"] == 0, rep
+        if empty_rank != rank:   # (a rank without masked phonemes has no backward: nothing crosses a stream)
+            assert rep["checks"] > (50 if mode == "rccl" else 10), rep
         assert tr.engine.status()["ln_exchange_timeouts"] == 0              # two processes share the GPU: hand-offs still arrive
         pieces = tr.engine.comm_pieces() if mode == "rccl" else None
         if fp8:
