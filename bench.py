@@ -231,6 +231,8 @@ def secondary_lines():
                         "workload": j["config"]["workload"], "dominant_kernel": rl.get("kernel"),
                         "dominant_frac": rl.get("frac"), "dominant_peak_TFLOPs": rl.get("peak"),
                         "loss_parity": j.get("loss_parity")}
+            if "fp8_clamped_calls" in j:
+                out[key]["fp8_clamped_calls"] = j["fp8_clamped_calls"]
             if key.endswith("fp8"):
                 out[key]["parity"] = ("loss within 2e-2 relative of this build's bf16 path and of the reference; whole-gradient "
                                       "relative L2 0.10-0.11, per tensor <= 0.25 (tests/test_gpu_fp8.py, tools/fp8_diag.py) - NOT "
@@ -825,6 +827,8 @@ def main():
         if secondary is not None:
             out["secondary"] = secondary
         if args.dtype == "fp8":
+            # per operand site: (calls in which values were clamped under the delayed scale, worst overshoot) - must be zeros
+            out["fp8_clamped_calls"] = eng.fp8_stats()
             out["config"]["parity"] = ("fp8 path: loss within 2e-2 relative and whole-gradient relative L2 0.10-0.11 of the bf16 "
                                        "path (tests/test_gpu_fp8.py, tools/fp8_diag.py), not 1e-3")
         sys.stdout.flush()

@@ -253,7 +253,7 @@ struct PlbEngine {
   // all layers at once, by the token-major weight-gradient GEMMs
   int64_t o_x8 = 0, o_a8 = 0, o_g8 = 0, o_c8 = 0, o_dp8 = 0, o_du8 = 0, o_dp18 = 0, o_dq8 = 0;
   int64_t o_wq8 = 0, o_wd8 = 0, o_w18 = 0, o_w28 = 0, o_w2T8 = 0, o_w1T8 = 0, o_wqT8 = 0, o_wdT8 = 0;
-  int64_t o_f8amax = 0, o_f8scale = 0, o_f8deq = 0;
+  int64_t o_f8amax = 0, o_f8scale = 0, o_f8deq = 0, o_f8stats = 0;
   int f8n = 0;
   bool infer = false;           // inference-only workspace: one layer of activations, no gradient stash
   int tok_steps = 0;            // AdamW steps the token head has taken (its own bias correction)
@@ -517,6 +517,7 @@ extern "C" int plb_create(const PlbConfig* cfg, PlbEngine** out) {
   }
   e->f8n = 8 * (int)L + 8;
   e->o_f8amax = cv.take((int64_t)e->f8n * 64 * 16 * 4); e->o_f8scale = cv.take(e->f8n * 4); e->o_f8deq = cv.take(e->f8n * 4);
+  e->o_f8stats = cv.take(8 * 8 * 4);   // per operand site: maxima history, clamped-call count, worst overshoot (rowops.hip: fp8_scales_kernel)
   e->ws_bytes = cv.off;
   *out = e;
   return 0;
@@ -675,7 +676,11 @@ static int fp8_update_scales(PlbEngine* e, hipStream_t s) {
   // X, A, G, C: e4m3, 448. Gradients (DP, DU, DP1, DQ): e5m2, mapped to HALF the format's range — a step whose gradients
   // are up to 2x the previous step's (a smaller batch: the loss is a mean over samples) still fits; five exponent bits
   // have the binade to spare. One launch for the whole site table.
-  TRY(plb_launch_fp8_scales2(f8_amax(e, 0), f8_scale(e, 0), f8_deq(e, 0), 8 * L, 448.f, L, 4 * L, 28672.f, s));
+  // Gradient sites: the scale comes from the LARGEST maximum of the last four calls (a call whose gradients are a multiple
+  // of the previous call's is clamped only beyond that), and every site counts the calls in which values were clamped
+  // (plb_fp8_stats): a clamped step is visible instead of silent.
+  TRY(plb_launch_fp8_scales2(f8_amax(e, 0), f8_scale(e, 0), f8_deq(e, 0), 8 * L, 448.f, L, 4 * L, 28672.f,
+                             e->at<float>(e->o_f8stats), 4, s));
   return 0;
 }
 
@@ -716,6 +721,8 @@ extern "C" int plb_set_fp8(PlbEngine* e, int32_t on, void* stream) {
   if (on && !e->fp8_on) {  // the first call afterwards runs in bf16 and calibrates the scales
     hipStream_t s = (hipStream_t)stream;
     HIPTRY(hipMemsetAsync(f8_amax(e, 0), 0, (size_t)e->f8n * F8_AMAX_WORDS * 4, s));
+    HIPTRY(hipMemsetAsync(e->at<float>(e->o_f8stats), 0, 8 * 8 * 4, s));
+    HIPTRY(hipMemsetAsync(f8_scale(e, 0), 0, (size_t)e->f8n * 4, s));   // "no scale yet": the calibration call's maxima are not overshoots
     e->fp8_ready = false;      // activation sites: armed by the first forward
     e->fp8_bwd_ready = false;  // gradient sites: armed by the first backward
     e->fp8_wstale = true;
@@ -727,6 +734,21 @@ extern "C" int plb_fp8_state(const PlbEngine* e, int32_t* enabled, int32_t* cali
   if (!e) return fail("plb_fp8_state: null engine");
   if (enabled) *enabled = e->fp8_on;
   if (calibrated) *calibrated = e->fp8_ready;
+  return 0;
+}
+
+// Per operand site (X, A, G, C in e4m3; dpre2, dU, dpre1, dQKV in e5m2): calls since plb_set_fp8 in which the site's values
+// exceeded the format's range under the delayed scale they were quantised with (those elements were clamped), and the
+// worst overshoot (true maximum x scale / format maximum; <= 1 = never clamped). Synchronises `stream`.
+extern "C" int plb_fp8_stats(PlbEngine* e, float clamped_calls[8], float worst_overshoot[8], void* stream) {
+  if (!e || !e->ws) return fail("plb_fp8_stats: engine not bound");
+  float st[64];
+  HIPTRY(hipMemcpyAsync(st, e->at<float>(e->o_f8stats), sizeof(st), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  HIPTRY(hipStreamSynchronize((hipStream_t)stream));
+  for (int i = 0; i < 8; ++i) {
+    if (clamped_calls) clamped_calls[i] = st[i * 8 + 4];
+    if (worst_overshoot) worst_overshoot[i] = st[i * 8 + 5];
+  }
   return 0;
 }
 

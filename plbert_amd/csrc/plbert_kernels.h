@@ -151,9 +151,11 @@ typedef struct {
 int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols, int ld, float* amax, hipStream_t stream);
 // group: runs of `group` consecutive sites share one scale (from the largest maximum of the run); 1 = every site its own
 int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, int group, hipStream_t stream);
-// the same with a second target for entries [n2, n) (n2 a multiple of group)
+// the same with a second target for entries [n2, n) (n2 a multiple of group). stats (or null): 8 floats per group — a
+// four-call history of the group's maxima (groups from hist_from on take their scale from its largest entry), the number
+// of calls whose values exceeded the format's range under the scale they were quantised with, the worst such ratio
 int plb_launch_fp8_scales2(float* amax, float* scale, float* deq, int n, float fmax, int group, int n2, float fmax2,
-                           hipStream_t stream);
+                           float* stats, int hist_from, hipStream_t stream);
 int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int cols, int ld, const float* scale, uint8_t* out, int ldo,
                         int bf8, hipStream_t stream);
 // the fp8 copies of up to 8 contiguous weight matrices in one launch: dst[i] = e4m3(src[i] * scale[i][0]); amax[i] (a site)

@@ -949,11 +949,17 @@ __global__ __launch_bounds__(256) void amax_kernel(const void* X, size_t rows, i
 // group > 1: sites come in runs of `group` entries (the L applications of the shared layer at one operand site) that share
 // ONE scale, formed from the largest maximum of the run — the weight-gradient GEMM sums products of two images over all
 // applications in one launch with one dequantisation factor, so every application's image must be on the same scale.
+// stats (or null): 8 floats per group — [0..3] the last four non-zero maxima of the group, [4] how many calls quantised
+// values beyond the format's range by more than the top value's rounding step (this call's true maximum x the scale it was
+// quantised with > 1.0625 fmt: those elements were clamped and it shows), [5] the worst such ratio, [6] maxima recorded so far (selects the history slot). Groups from hist_from on
+// (the gradient sites) take their scale from the LARGEST maximum of the history instead of the last one: a step whose
+// gradients are several times the previous step's (a short final batch, the step after a validation pass, a loss
+// spike) is then clamped only if it exceeds everything seen in four calls, and the clamp is counted either way.
 __global__ __launch_bounds__(64) void fp8_scales_kernel(float* amax, float* scale, float* deq, int n, float fmax, int group,
-                                                        int n2, float fmax2) {
+                                                        int n2, float fmax2, float* stats, int hist_from, float fmt, float fmt2) {
   const int g0 = blockIdx.x * group, lane = threadIdx.x;
   if (g0 >= n) return;
-  if (g0 >= n2) fmax = fmax2;   // entries [n2, n): the second format's target (one launch for both halves of the site table)
+  if (g0 >= n2) { fmax = fmax2; fmt = fmt2; }   // entries [n2, n): the second format's target (one launch for both halves of the site table)
   float a = 0.f;
   for (int i = g0; i < g0 + group && i < n; ++i) {
     float* w = amax + (size_t)i * F8_SLOTS * F8_STRIDE + lane * F8_STRIDE;
@@ -961,11 +967,28 @@ __global__ __launch_bounds__(64) void fp8_scales_kernel(float* amax, float* scal
     w[0] = 0.f;
   }
   a = wave_max(a);
-  if (a > 0.f && a < INFINITY)
-    for (int i = g0 + lane; i < g0 + group && i < n; i += 64) {
-      scale[i] = fmax / a;
-      deq[i] = a / fmax;
+  if (a > 0.f && a < INFINITY) {
+    float target = a;
+    if (stats) {
+      float* st = stats + (size_t)blockIdx.x * 8;
+      if (lane == 0) {
+        const float used = scale[g0];               // the scale this call's values were quantised with (0 before the first)
+        const float ratio = a * used / fmt;
+        if (ratio > 1.0625f) { st[4] += 1.f; st[5] = fmaxf(st[5], ratio); }   // beyond the top value by more than its rounding step
+        float h[4] = {st[0], st[1], st[2], st[3]};
+        const int slot = (int)st[6] & 3;
+        h[slot] = a;
+        st[slot] = a;
+        st[6] += 1.f;
+        if ((int)blockIdx.x >= hist_from) target = fmaxf(fmaxf(h[0], h[1]), fmaxf(h[2], h[3]));
+      }
+      target = __shfl(target, 0);
     }
+    for (int i = g0 + lane; i < g0 + group && i < n; i += 64) {
+      scale[i] = fmax / target;
+      deq[i] = target / fmax;
+    }
+  }
 }
 // out[r][c] = fp8(x[r][c] * scale): 8 elements per thread
 template <bool BF16>
@@ -1250,14 +1273,15 @@ extern "C" int plb_launch_amax(const void* x, int is_bf16, size_t rows, int cols
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_fp8_scales2(float* amax, float* scale, float* deq, int n, float fmax, int group, int n2, float fmax2,
-                                      hipStream_t stream) {
+                                      float* stats, int hist_from, hipStream_t stream) {
   if (n <= 0) return 0;
   if (group < 1) group = 1;
-  hipLaunchKernelGGL(fp8_scales_kernel, dim3((n + group - 1) / group), dim3(64), 0, stream, amax, scale, deq, n, fmax, group, n2, fmax2);
+  hipLaunchKernelGGL(fp8_scales_kernel, dim3((n + group - 1) / group), dim3(64), 0, stream, amax, scale, deq, n, fmax, group, n2, fmax2,
+                     stats, hist_from, 448.f, 57344.f);
   return LAUNCH_OK();
 }
 extern "C" int plb_launch_fp8_scales(float* amax, float* scale, float* deq, int n, float fmax, int group, hipStream_t stream) {
-  return plb_launch_fp8_scales2(amax, scale, deq, n, fmax, group, n, fmax, stream);
+  return plb_launch_fp8_scales2(amax, scale, deq, n, fmax, group, n, fmax, nullptr, 0, stream);
 }
 extern "C" int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int cols, int ld, const float* scale,
                                    uint8_t* out, int ldo, int bf8, hipStream_t stream) {

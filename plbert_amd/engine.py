@@ -288,6 +288,15 @@ class HipEngine:
         _lib.check(self.L.plb_fp8_state(self.handle, C.byref(a), C.byref(b)), "plb_fp8_state")
         return bool(a.value), bool(b.value)
 
+    FP8_SITES = ("x", "a", "gelu_u", "context", "dpre2", "dU", "dpre1", "dQKV")
+
+    def fp8_stats(self):
+        """{site: (calls in which values were clamped, worst overshoot)} since set_fp8 (plb_fp8_stats; synchronises)."""
+        c, w = (C.c_float * 8)(), (C.c_float * 8)()
+        with torch.cuda.device(self.device):
+            _lib.check(self.L.plb_fp8_stats(self.handle, c, w, self._stream()), "plb_fp8_stats")
+        return {n: (int(c[i]), round(float(w[i]), 4)) for i, n in enumerate(self.FP8_SITES)}
+
     @property
     def token_head_steps(self):
         return int(self.L.plb_token_head_steps(self.handle))

@@ -444,6 +444,91 @@ def test_fp8_step_on_shapes_without_fused_layernorm_forms(B, S, lens):
     assert eng.status()["ln_exchange_timeouts"] == 0
 
 
+def test_fp8_weight_gradients_with_padded_token_rows_after_a_larger_call():
+    """The fp8 weight-gradient GEMMs sum over ALL Tp = ceil128(T) rows of every application, pad rows included, so they
+    rely on: every e5m2 gradient image has zero pad rows (dq8 memset, ln_bwd_wide zeroes its out8, the fused forms compute
+    zeros), and the pad rows of the e4m3 activation images hold FINITE bytes (x8 / a8 / g8 are rewritten over all Tp rows;
+    c8, the attention context image, only over the T valid rows — its pad rows keep what an earlier, LARGER call left
+    there). 7 x 500 = 3,500 tokens -> Tp = 3,584, 12 x 3,584 = 43,008 stacked rows: the images path (tn8), ragged rows,
+    84 pad rows per application that the 8 x 512 calls before it filled with real activations. Stale bytes times zero
+    gradients must add nothing: gradients as close to the bf16 path as on a fresh engine."""
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                                  max_position_embeddings=512, num_hidden_layers=12)
+    sd = plbert_amd.deterministic_state_dict(cfg, 188, seed=9)
+
+    def batch(B, S, lens, seed):
+        labels, masked, _, idx = plbert_amd.synthetic_batch(B, S, seed=seed)
+        idx = [[i for i in ix if i < n] or [0] for ix, n in zip(idx, lens)]
+        for b, n in enumerate(lens):
+            labels[b, n:] = 0
+            masked[b, n:] = 0
+        off, flat = plbert_amd.masked_indices_to_csr(idx)
+        return (masked, labels, np.asarray(lens, np.int32), off, flat, int(off[-1]))
+
+    big = batch(8, 512, [512] * 8, seed=3)
+    small = batch(7, 500, [500, 500, 480, 500, 333, 500, 91], seed=4)
+    ref = HipEngine(cfg, 188, 0, max_batch=8, max_seq=512)
+    ref.load_state_dict(sd)
+    l_ref = float(ref.loss_fwd_bwd(*small).item())
+    n = ref.trainable
+    g_ref = ref.grads[:n].clone()
+    res = {}
+    for stale in (False, True):
+        eng = HipEngine(cfg, 188, 0, max_batch=8, max_seq=512)
+        eng.load_state_dict(sd)
+        eng.set_fp8(True)
+        if stale:   # fills every image's rows [0, 4096) of every application, pad rows of the small call included
+            eng.loss_fwd_bwd(*big)
+            eng.loss_fwd_bwd(*big)
+        eng.loss_fwd_bwd(*small)                      # (fresh engine: the calibration call)
+        l8 = float(eng.loss_fwd_bwd(*small).item())
+        l8 = float(eng.loss_fwd_bwd(*small).item())   # scales learnt on this very batch in both engines
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(eng.grads[:n]).all())
+        res[stale] = (l8, rel_l2(eng.grads[:n], g_ref), eng.grads[:n].clone())
+        assert eng.status()["ln_exchange_timeouts"] == 0
+        del eng
+    for stale in (False, True):
+        l8, r, _ = res[stale]
+        assert abs(l8 - l_ref) / l_ref < 2e-2, (stale, l8, l_ref)
+        assert r < 0.15, (stale, r)                   # whole-gradient distance of the fp8 path: 0.10-0.11 everywhere
+    # the same call on the same weights with the same scales' history on this batch: only rounding chaos may differ
+    assert abs(res[True][1] - res[False][1]) < 0.02, (res[True][1], res[False][1])
+
+
+def test_fp8_clamped_calls_are_counted_and_the_gradient_history_holds_the_scale():
+    """Delayed scaling has a blind spot: a call whose gradients are several times the previous call's is quantised under the
+    old scale and the excess is clamped (include/plbert.h: plb_fp8_stats). One sample after sixteen: the loss is a mean
+    over samples, so every gradient is ~16x larger -> beyond the 2x headroom of the e5m2 sites: that call must be COUNTED
+    (clamped_calls, worst overshoot > 1), the next call on the same batch must not be (the scale has followed), and going
+    back to the large batch must not clamp either — the four-call history keeps the larger maximum."""
+    cfg = plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
+                                  max_position_embeddings=512, num_hidden_layers=2)
+    sd = plbert_amd.deterministic_state_dict(cfg, 188, seed=9)
+    eng = HipEngine(cfg, 188, 0, max_batch=16, max_seq=512)
+    eng.load_state_dict(sd)
+    eng.set_fp8(True)
+
+    def call(B):
+        labels, masked, lens, idx = plbert_amd.synthetic_batch(B, 512, seed=21)
+        off, flat = plbert_amd.masked_indices_to_csr(idx)
+        return float(eng.loss_fwd_bwd(masked, labels, None, off, flat, int(off[-1])).item())
+
+    grad_sites = ("dpre2", "dU", "dpre1", "dQKV")
+    call(16); call(16); call(16)
+    st = eng.fp8_stats()
+    assert all(st[k] == (0, 0.0) for k in st), st                       # steady batches: nothing clamped anywhere
+    call(2)                                                              # 8x the gradients under the 16-sample scales
+    st = eng.fp8_stats()
+    assert all(st[k][0] == 1 and st[k][1] > 1.5 for k in grad_sites), st
+    call(2)
+    assert all(eng.fp8_stats()[k][0] == 1 for k in grad_sites)          # the scale has followed
+    l_back = call(16)
+    st = eng.fp8_stats()
+    assert all(st[k][0] == 1 for k in grad_sites), st                   # back to small gradients: coarser, never clamped
+    assert np.isfinite(l_back)
+
+
 def _fp8_vs_bf16(cfg, B, S, num_tokens=0, seed=5):
     labels, masked, lens, idx = plbert_amd.synthetic_batch(B, S, seed=seed)
     sd = plbert_amd.deterministic_state_dict(cfg, 188, num_tokens, seed=seed)
