@@ -527,20 +527,19 @@ extern "C" int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }
 
-// The two-kernel form below is the default. The single-kernel backward (attn_bwd_fused.hip, S <= 512) is selected by
-// PLBERT_ATTN_BWD=fused or plb_set_attn_bwd_fused(1): measured in round 3 it ties the two kernels where its grid fills
-// the chip in whole rounds (16 x 16 heads: 78-84 vs 83 us) and loses where it does not (32 x 12 heads = 1.5 rounds:
-// 143-147 vs 113-128 us) — DESIGN.md §6 says why (register file and LDS bandwidth at head_dim 64).
-static int g_bwd_fused = -1;
-extern "C" void plb_set_attn_bwd_fused(int on) { g_bwd_fused = on ? 1 : 0; }
-
-extern "C" int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream) {
-  if (check_attn(p) || p->lddctx % 8 || p->lddqkv % 8 || (!p->dqkv && !p->dqkv8) || (p->dqkv8 && (!p->dqkv_scale || p->lddqkv8 % 8))) return 1;
-  if (g_bwd_fused < 0) {
-    const char* e = getenv("PLBERT_ATTN_BWD");
-    g_bwd_fused = (e && !strcmp(e, "fused")) ? 1 : 0;
-  }
-  if (g_bwd_fused && p->S <= 512 && p->dqkv && !p->dqkv8) return plb_launch_attn_bwd_fused(p, stream);  // (no fp8 image in the fused form)
+// Two forms of the backward. The two-kernel form (dQ kernel + dK/dV kernel, any S) runs 4 workgroups per CU and packs
+// any grid; the single-kernel form (attn_bwd_fused.hip, S <= 512: five products instead of seven, one exponential pass)
+// needs a whole CU per (batch, head), so it pays only where B x heads fills the 256 CUs in (nearly) whole rounds —
+// measured (profiles/r03_attn_bwd_fused_vs_split.txt, r05_attn_bwd_policy.txt): 16 x 16 heads = exactly one round: 74-78 vs
+// 83 us; 32 x 12 = 1.5 rounds: 143-149 vs 127 us. Policy per call (PLBERT_ATTN_BWD = fused | split | auto, default auto;
+// plb_set_attn_bwd_fused(1 / 0 / -1) likewise):
+//   auto: S in (384, 512] and the last round of B x heads at least 90 % full -> fused; else, if at least one FULL round of
+//         256 items fits and the remainder is at most half a round, the first floor(256 / heads) samples per round take
+//         the fused kernel and the remaining samples the two-kernel form (PLBERT_ATTN_BWD_HYBRID=0 turns this off);
+//         everything else -> two kernels. An fp8 call that needs bf16 rows AND the image -> two kernels.
+static int g_bwd_fused = -2;   // -2: read the environment; -1 auto, 0 split, 1 fused
+extern "C" void plb_set_attn_bwd_fused(int on) { g_bwd_fused = on < 0 ? -1 : (on ? 1 : 0); }
+static int launch_attn_bwd_split(const PlbAttn* p, hipStream_t stream) {
   dim3 grid(((p->S + 127) / 128) * p->NH * p->B), block(256);
   // algorithmic work of the backward = 4 products (dP, dQ, dV, dK); the S recomputation in each
   // kernel and the second dP are not credited
@@ -553,4 +552,48 @@ extern "C" int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream) {
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, block, 0, stream, *p);
   plb_prof_end(tok, stream);
   return hipGetLastError() == hipSuccess ? 0 : 2;
+}
+// samples [b0, b0 + nb) of a call as a call of their own
+static PlbAttn attn_samples(const PlbAttn* p, int b0, int nb) {
+  PlbAttn q = *p;
+  const size_t t0 = (size_t)b0 * p->S;
+  q.B = nb;
+  q.qkv = p->qkv + t0 * p->ldqkv;
+  q.ctx = p->ctx + t0 * p->ldctx;
+  q.dctx = p->dctx + t0 * p->lddctx;
+  if (p->dqkv) q.dqkv = p->dqkv + t0 * p->lddqkv;
+  if (p->dqkv8) q.dqkv8 = p->dqkv8 + t0 * p->lddqkv8;
+  if (p->lengths) q.lengths = p->lengths + b0;
+  q.lse = p->lse + (size_t)b0 * p->NH * p->S;
+  if (p->delta) q.delta = p->delta + (size_t)b0 * p->NH * p->S;
+  if (p->colpart) q.colpart = p->colpart + (size_t)b0 * ((p->S + 127) / 128) * 4 * (3 * p->H);
+  return q;
+}
+
+extern "C" int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream) {
+  if (check_attn(p) || p->lddctx % 8 || p->lddqkv % 8 || (!p->dqkv && !p->dqkv8) || (p->dqkv8 && (!p->dqkv_scale || p->lddqkv8 % 8))) return 1;
+  static int hybrid_on = -1;
+  if (g_bwd_fused == -2) {
+    const char* e = getenv("PLBERT_ATTN_BWD");
+    g_bwd_fused = (e && !strcmp(e, "fused")) ? 1 : (e && !strcmp(e, "split")) ? 0 : -1;
+  }
+  if (hybrid_on < 0) { const char* e = getenv("PLBERT_ATTN_BWD_HYBRID"); hybrid_on = !(e && !strcmp(e, "0")); }
+  const bool can_fuse = p->S <= 512 && !(p->dqkv && p->dqkv8);
+  if (!can_fuse || g_bwd_fused == 0) return launch_attn_bwd_split(p, stream);
+  if (g_bwd_fused == 1) return plb_launch_attn_bwd_fused(p, stream);
+  if (p->S <= 384) return launch_attn_bwd_split(p, stream);
+  const int items = p->B * p->NH, rounds = (items + 255) / 256;
+  if (items * 10 >= rounds * 256 * 9) return plb_launch_attn_bwd_fused(p, stream);
+  // hybrid: whole samples worth (nearly) full rounds to the fused kernel, the rest to the two kernels
+  const int per_round = 256 / p->NH;                      // samples whose (batch, head) items fit one round
+  const int full = per_round > 0 ? (p->B / per_round) : 0; // full rounds available
+  const int nb_f = full * per_round, rest = p->B - nb_f;
+  if (hybrid_on && full >= 1 && per_round * p->NH * 10 >= 256 * 9 && rest * p->NH <= 160) {
+    const PlbAttn a = attn_samples(p, 0, nb_f);
+    const int rc = plb_launch_attn_bwd_fused(&a, stream);
+    if (rc || rest == 0) return rc;
+    const PlbAttn b = attn_samples(p, nb_f, rest);
+    return launch_attn_bwd_split(&b, stream);
+  }
+  return launch_attn_bwd_split(p, stream);
 }

@@ -60,7 +60,11 @@ DEVI bf16x8 lds_tr2(uint32_t a0, uint32_t a1) { return join_tr(lds_read_tr16_add
 #define FUSED_DBG 0   // timing builds: 1 no exponentials, 2 no MFMA (attn_common.h: ATTN_DBG); 256 no dQ phase, 512 no key-owner phase
 #endif
 
+// F8: the call also (or only) writes the e5m2 image of dQKV (fp8 mode); a separate instantiation, so that the bf16 build
+// does not carry the image's scale, maximum and pointers through a loop that runs at the full register file
+template <int MODE>   // 0: bf16 rows, 1: the e5m2 image alone (fp8 training call), 2: both
 __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(PlbAttn p) {
+  constexpr bool F8 = MODE != 0, B16 = MODE != 1;
   __shared__ __attribute__((aligned(16))) unsigned char smem[FB_TOTAL];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,10 +95,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(PlbAttn p) {
   const bool st_do = wave >= 2;
   const char* const st_base = st_do ? (const char*)(p.dctx + hd * 64 + tok0 * ldo) : (const char*)(p.qkv + hd * 64 + tok0 * ld);
   const int st_ld = st_do ? ldo : ld;
-  const int st_r0 = 16 * (wave & 1) + (lane >> 3), st_r1 = st_r0 + 8;
-  const int st_c0 = ((lane & 7) ^ du_f(st_r0)) * 8, st_c1 = ((lane & 7) ^ du_f(st_r1)) * 8;
-  const uint32_t st_v0 = (uint32_t)(st_r0 * st_ld + st_c0) * 2, st_v1 = (uint32_t)(st_r1 * st_ld + st_c1) * 2;
+  uint32_t st_v0, st_v1;
+  {
+    const int st_r0 = 16 * (wave & 1) + (lane >> 3), st_r1 = st_r0 + 8;
+    const int st_c0 = ((lane & 7) ^ du_f(st_r0)) * 8, st_c1 = ((lane & 7) ^ du_f(st_r1)) * 8;
+    st_v0 = (uint32_t)(st_r0 * st_ld + st_c0) * 2; st_v1 = (uint32_t)(st_r1 * st_ld + st_c1) * 2;
+  }
   const uint32_t st_lds = lds_base + FB_STG + (wave >> 1) * 4096 + (wave & 1) * 2048;
+  // Lane constants that only a rare path or the epilogue needs are NOT kept across the query-block loop (the loop runs at the
+  // full 512 registers: carried along they were 21 spilled registers, reloaded from scratch inside it). They are
+  // re-derived where used from the lane id (mbcnt) behind an opaque copy, which keeps hipcc from hoisting them back.
+#define LANE_ID(x) int x = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); OPAQUE(x)
 #define F_STAGE(ST, qb_)                                                                              \
   do {                                                                                                \
     const int q0_ = (qb_) * 32;                                                                       \
@@ -103,23 +114,27 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(PlbAttn p) {
       const char* sb_ = st_base + (size_t)q0_ * st_ld * 2;                                            \
       DMA16(sb_, st_v0, l_); DMA16(sb_, st_v1, l_ + 1024);                                            \
     } else { /* the block that crosses S: rows are clamped, every lane computes its own offsets */    \
-      const int a0_ = min(q0_ + st_r0, S - 1), a1_ = min(q0_ + st_r1, S - 1);                         \
-      DMA16(st_base, (uint32_t)(a0_ * st_ld + st_c0) * 2, l_);                                        \
-      DMA16(st_base, (uint32_t)(a1_ * st_ld + st_c1) * 2, l_ + 1024);                                 \
+      LANE_ID(ln_);                                                                                   \
+      const int r0_ = 16 * (wave & 1) + (ln_ >> 3), r1_ = r0_ + 8;                                    \
+      const int c0_ = ((ln_ & 7) ^ du_f(r0_)) * 8, c1_ = ((ln_ & 7) ^ du_f(r1_)) * 8;                 \
+      const int a0_ = min(q0_ + r0_, S - 1), a1_ = min(q0_ + r1_, S - 1);                             \
+      DMA16(st_base, (uint32_t)(a0_ * st_ld + c0_) * 2, l_);                                          \
+      DMA16(st_base, (uint32_t)(a1_ * st_ld + c1_) * 2, l_ + 1024);                                   \
     }                                                                                                 \
   } while (0)
   // ---- row statistics of one block: thread t takes row t>>3, 8 columns; delta = rowsum(dO∘O), LSE copied
-  const bf16_t* const g_do = p.dctx + hd * 64 + tok0 * ldo + (tid & 7) * 8;
-  const bf16_t* const g_o = p.ctx + hd * 64 + tok0 * p.ldctx + (tid & 7) * 8;
+  // (wave-uniform bases + 32-bit lane offsets: one address register per load instead of a 64-bit pointer per tensor)
+  const bf16_t* const g_do = p.dctx + hd * 64 + tok0 * ldo;
+  const bf16_t* const g_o = p.ctx + hd * 64 + tok0 * p.ldctx;
   const float* const g_lse = p.lse + ((size_t)b * p.NH + hd) * S;
   uint4 sv_do, sv_o;
   float sv_lse = 0.f;
 #define F_STAT_LOAD(qb_)                                                                              \
   do {                                                                                                \
     const int r_ = min((qb_) * 32 + (tid >> 3), S - 1);                                               \
-    sv_do = *(const uint4*)(g_do + (size_t)r_ * ldo);                                                 \
-    sv_o = *(const uint4*)(g_o + (size_t)r_ * p.ldctx);                                               \
-    if (tid < 32) sv_lse = g_lse[min((qb_) * 32 + tid, S - 1)];                                       \
+    sv_do = *(const uint4*)(g_do + (uint32_t)(r_ * ldo + (tid & 7) * 8));                             \
+    sv_o = *(const uint4*)(g_o + (uint32_t)(r_ * p.ldctx + (tid & 7) * 8));                           \
+    if (tid < 32) sv_lse = g_lse[(uint32_t)min((qb_) * 32 + tid, S - 1)];                             \
   } while (0)
 #define F_STAT_STORE(ST, qb_)                                                                         \
   do {                                                                                                \
@@ -128,10 +143,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(PlbAttn p) {
     d_ += bf_lo(sv_do.z) * bf_lo(sv_o.z) + bf_hi(sv_do.z) * bf_hi(sv_o.z);                            \
     d_ += bf_lo(sv_do.w) * bf_lo(sv_o.w) + bf_hi(sv_do.w) * bf_hi(sv_o.w);                            \
     d_ += __shfl_xor(d_, 1, 64); d_ += __shfl_xor(d_, 2, 64); d_ += __shfl_xor(d_, 4, 64);            \
+    int t_ = tid; OPAQUE(t_);   /* the two LDS addresses are formed here, not carried across the loop */ \
     float* st_ = (float*)(smem + FB_STAT + (ST) * 256);  /* [bias 32 | -delta 32] */                    \
-    if ((tid & 7) == 0) st_[32 + (tid >> 3)] = -d_;                                                   \
+    if ((t_ & 7) == 0) st_[32 + (t_ >> 3)] = -d_;                                                     \
     /* log2-domain bias of the row: P = exp2(S*c + bias); a query past the length gets P = 0 */       \
-    if (tid < 32) st_[tid] = ((qb_) * 32 + tid < len) ? sv_lse * sl2 : -1e30f;                        \
+    if (t_ < 32) st_[t_] = ((qb_) * 32 + t_ < len) ? sv_lse * sl2 : -1e30f;                           \
   } while (0)
 
   const int NQ = (len + 31) >> 5;   // query blocks with work (queries past the length carry exactly zero dO in this model)
@@ -213,7 +229,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(PlbAttn p) {
       }
   }
   float colq[4] = {0.f, 0.f, 0.f, 0.f};   // column sums of the dQ values this lane stored (bias gradient partial)
-  bf16_t* const g_dq = p.dqkv + tok0 * p.lddqkv + hd * 64 + 16 * wave + 4 * (lane >> 4);
+  // dQ rows leave from a wave-uniform base + ONE 32-bit lane offset (query lane&15 of the half, d 16w + 4(lane>>4) ..+3);
+  // fp8 calls: the e5m2 image of the same values (AS ROUNDED to bf16) x the site's scale, 4 bytes per lane; the bf16 rows
+  // only if somebody reads them (p.dqkv)
+  bf16_t* const g_dq = B16 ? p.dqkv + tok0 * p.lddqkv + hd * 64 + 16 * wave : nullptr;
+  uint8_t* const g_dq8 = F8 ? p.dqkv8 + tok0 * p.lddqkv8 + hd * 64 + 16 * wave : nullptr;
+  const float qs8 = F8 ? p.dqkv_scale[0] : 1.0f;
+  float amax8 = 0.f;
 
   F_STAT_STORE(0, 0);
   DMA_WAIT();
@@ -336,8 +358,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(PlbAttn p) {
       o_.x = pack_bf2(a[0] * p.scale, a[1] * p.scale);                                                           \
       o_.y = pack_bf2(a[2] * p.scale, a[3] * p.scale);                                                           \
       if (q_ < S) {                                                                                              \
-        *(uint2*)(g_dq + (size_t)q_ * p.lddqkv) = o_;                                                            \
-        colq[0] += bf_lo(o_.x); colq[1] += bf_hi(o_.x); colq[2] += bf_lo(o_.y); colq[3] += bf_hi(o_.y);          \
+        const float f0_ = bf_lo(o_.x), f1_ = bf_hi(o_.x), f2_ = bf_lo(o_.y), f3_ = bf_hi(o_.y);                  \
+        if (B16) *(uint2*)(g_dq + (uint32_t)(q_ * p.lddqkv + 4 * (lane >> 4))) = o_;                            \
+        if (F8) {                                                                                                \
+          *(uint32_t*)(g_dq8 + (uint32_t)(q_ * p.lddqkv8 + 4 * (lane >> 4))) =                                   \
+              pack_fp8x4(f0_ * qs8, f1_ * qs8, f2_ * qs8, f3_ * qs8, true);                                      \
+          amax8 = fmaxf(amax8, fmaxf(fmaxf(fabsf(f0_), fabsf(f1_)), fmaxf(fabsf(f2_), fabsf(f3_))));             \
+        }                                                                                                        \
+        colq[0] += f0_; colq[1] += f1_; colq[2] += f2_; colq[3] += f3_;                                          \
       }                                                                                                          \
     }                                                                                                            \
   } while (0)
@@ -409,9 +437,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(PlbAttn p) {
   }
 #endif
 
-  // ---- epilogue. Query rows past the last block with work: dQ = 0 (the dX GEMM reads every row)
-  for (int r = NQ * 32 + (tid >> 3); r < S; r += 32)
-    *(uint4*)(p.dqkv + (tok0 + r) * p.lddqkv + hd * 64 + (tid & 7) * 8) = make_uint4(0, 0, 0, 0);
+  // ---- epilogue. Query rows past the last block with work: dQ = 0 (the dX GEMM reads every row). Lane-derived values are
+  // formed afresh (LANE_ID): nothing of the prologue's lane arithmetic stays live across the loop for these lines.
+  LANE_ID(lane_e);
+  const int tid_e = wave * 64 + lane_e;
+  for (int r = NQ * 32 + (tid_e >> 3); r < S; r += 32) {
+    if (B16) *(uint4*)(p.dqkv + (tok0 + r) * p.lddqkv + hd * 64 + (tid_e & 7) * 8) = make_uint4(0, 0, 0, 0);
+    if (F8) *(uint2*)(p.dqkv8 + (tok0 + r) * p.lddqkv8 + hd * 64 + (tid_e & 7) * 8) = make_uint2(0, 0);
+  }
   // dK, dV of this wave's four key blocks through the per-wave transpose patch (the exchange images are free now)
   bf16_t* patch = (bf16_t*)(smem + FB_EXCH) + wave * (32 * 72);
   const bool accq = p.colpart_accumulate != 0;
@@ -421,15 +454,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(PlbAttn p) {
     int rows_valid = S - key0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
     float* cp = (p.colpart && wave < QT) ? p.colpart + ((size_t)(b * QT + wave) * 4 + kb) * (3 * H) + hd * 64 : nullptr;
     if (rows_valid > 0) {
-      bf16_t* out = p.dqkv + (tok0 + key0) * p.lddqkv + hd * 64;
-      store_transposed(dk[kb][0], dk[kb][1], p.scale, patch, out + H, p.lddqkv, rows_valid, lane, cp ? cp + H : nullptr, accq);
+      bf16_t* out = B16 ? p.dqkv + (tok0 + key0) * p.lddqkv + hd * 64 : nullptr;
+      uint8_t* out8 = F8 ? p.dqkv8 + (tok0 + key0) * p.lddqkv8 + hd * 64 : nullptr;
+      const Out8 ok8 = {out8 ? out8 + H : nullptr, p.lddqkv8, qs8, true}, ov8 = {out8 ? out8 + 2 * H : nullptr, p.lddqkv8, qs8, true};
+      store_transposed<false, true>(dk[kb][0], dk[kb][1], p.scale, patch, out ? out + H : nullptr, p.lddqkv, rows_valid, lane_e,
+                                    cp ? cp + H : nullptr, accq, F8 ? &ok8 : nullptr, &amax8);
       __builtin_amdgcn_wave_barrier();
-      store_transposed(dv[kb][0], dv[kb][1], 1.0f, patch, out + 2 * H, p.lddqkv, rows_valid, lane, cp ? cp + 2 * H : nullptr, accq);
+      store_transposed<false, true>(dv[kb][0], dv[kb][1], 1.0f, patch, out ? out + 2 * H : nullptr, p.lddqkv, rows_valid, lane_e,
+                                    cp ? cp + 2 * H : nullptr, accq, F8 ? &ov8 : nullptr, &amax8);
       __builtin_amdgcn_wave_barrier();
     } else if (cp && !accq) {
-      cp[H + lane] = 0.f;
-      cp[2 * H + lane] = 0.f;
+      cp[H + lane_e] = 0.f;
+      cp[2 * H + lane_e] = 0.f;
     }
+  }
+  if (F8 && p.dqkv_amax) {
+    amax8 = wave_max(amax8);
+    if (lane_e == 0) atomic_max_abs(p.dqkv_amax, amax8, blockIdx.x * 4 + wave);
   }
   // bias-gradient partial of the Q block: the sums of this workgroup go to row 0 of the sample's rows, the others get 0
   if (p.colpart) {
@@ -440,13 +481,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(PlbAttn p) {
       colq[r] = v;
     }
     float* row0 = p.colpart + (size_t)(b * QT) * 4 * (3 * H) + hd * 64;
-    if ((lane & 15) == 0) {
-      float* d = row0 + 16 * wave + 4 * (lane >> 4);
+    if ((lane_e & 15) == 0) {
+      float* d = row0 + 16 * wave + 4 * (lane_e >> 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) d[r] = accq ? d[r] + colq[r] : colq[r];
     }
     if (!accq)
-      for (int rr = 1 + (tid >> 6); rr < 4 * QT; rr += 4) row0[(size_t)rr * (3 * H) + lane] = 0.f;
+      for (int rr = 1 + wave; rr < 4 * QT; rr += 4) row0[(size_t)rr * (3 * H) + lane_e] = 0.f;
   }
 }
 
@@ -456,12 +497,17 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_fused_kernel(PlbAttn p) {
 extern "C" int plb_launch_attn_bwd_fused(const PlbAttn* p, hipStream_t stream) {
   if (p->H != p->NH * 64 || p->S < 1 || p->S > 512 || p->B < 1) return 1;
   if (p->ldqkv % 8 || p->ldctx % 8 || p->lddctx % 8 || p->lddqkv % 8) return 1;
+  if ((!p->dqkv && !p->dqkv8) || (p->dqkv8 && (!p->dqkv_scale || p->lddqkv8 % 8))) return 1;
   dim3 grid(p->NH * p->B), block(256);
   const double unit = (double)p->B * p->NH * (double)p->S * p->S * 64.0;
   const double io = 2.0 * p->B * p->S * (double)p->H;
   // algorithmic work of the backward = 4 products (dP, dQ, dV, dK); the S recomputation is not credited
   const int tok = plb_prof_begin(PLB_K_ATTN_BWD, stream, 8.0 * unit, 6.0 * io);
-  hipLaunchKernelGGL(attn_bwd_fused_kernel, grid, block, 0, stream, *p);
+  // (bf16 rows AND the image in one call — an fp8 call whose weight gradients read bf16 operands — would need 4 more
+  // registers than the file has: that combination takes the two-kernel form, plb_launch_attn_bwd)
+  if (p->dqkv && p->dqkv8) return 1;
+  if (!p->dqkv8) hipLaunchKernelGGL(attn_bwd_fused_kernel<0>, grid, block, 0, stream, *p);
+  else hipLaunchKernelGGL(attn_bwd_fused_kernel<1>, grid, block, 0, stream, *p);
   plb_prof_end(tok, stream);
   return hipGetLastError() == hipSuccess ? 0 : 2;
 }

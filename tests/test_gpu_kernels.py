@@ -127,11 +127,12 @@ def test_gemm_tn_big(Mtot, N, K, splits, rps):
 
 @pytest.fixture
 def bwd_form(request):
-    """Selects the attention backward: 0 = dq + dkv kernels (the default), 1 = the single-kernel form (S <= 512)."""
+    """Forces the attention backward's form: 0 = dq + dkv kernels, 1 = the single-kernel form (S <= 512); afterwards the
+    per-shape policy (-1) is back."""
     L = _lib.lib()
     L.plb_set_attn_bwd_fused(int(request.param))
     yield int(request.param)
-    L.plb_set_attn_bwd_fused(0)
+    L.plb_set_attn_bwd_fused(-1)
 
 
 @pytest.mark.parametrize("bwd_form", [1, 0], indirect=True)
@@ -234,6 +235,108 @@ def test_attention_race_screen(bwd_form):
             assert rel_l2(dqkv.float(), grad(dctx)) < 1.5e-2
         else:
             assert all(torch.equal(a, b) for a, b in zip(got, first))
+
+
+@pytest.mark.parametrize("B,NH,nf", [(16, 16, 16), (32, 12, 21), (8, 12, 0), (22, 12, 21)])
+def test_attention_bwd_policy_and_hybrid_split(B, NH, nf):
+    """The per-shape policy (attn.hip: plb_launch_attn_bwd); nf = samples the single-kernel form must take. B x heads that
+    fills the CUs in whole rounds takes it entirely (16 x 16 = 256 items = one round); a batch with at least one (nearly)
+    full round of whole samples and a short remainder is SPLIT BY SAMPLE between the two forms (32 x 12: 21 samples = 252
+    items fused, 11 two-kernel; 22 x 12: 21 + 1); small grids take the two kernels (8 x 12 = 96 items). Whatever the policy picks must equal the forced two-kernel result on the samples each form handled —
+    the fused rows bitwise equal to a forced-fused call, the others bitwise equal to a forced-split call — including the
+    bias-gradient partial rows."""
+    L = _lib.lib()
+    S = 512
+    H = NH * 64
+    QT = 4
+    qkv = randbf(B * S, 3 * H, scale=1.0, seed=51)
+    lengths = torch.full((B,), S, dtype=torch.int32, device=DEV)
+    lengths[B - 1] = 300
+    lengths[0] = 449
+    p, ctx, lse = attn_args(qkv, lengths, B, S, NH)
+    assert L.plb_launch_attn_fwd(C.byref(p), stream()) == 0
+    dctx = randbf(B * S, H, seed=52)
+    qmask = (torch.arange(S, device=DEV)[None, :] < lengths[:, None]).reshape(B * S, 1)
+    dctx = dctx * qmask.to(dctx.dtype)
+    delta = torch.zeros((B, NH, S), dtype=torch.float32, device=DEV)
+    outs = {}
+    for form in (1, 0, -1):
+        dqkv = torch.full((B * S, 3 * H), 7.0, dtype=torch.bfloat16, device=DEV)
+        colp = torch.full((B * QT * 4, 3 * H), 3.0, dtype=torch.float32, device=DEV)
+        p.dctx, p.lddctx, p.delta, p.dqkv, p.lddqkv = dctx.data_ptr(), H, delta.data_ptr(), dqkv.data_ptr(), 3 * H
+        p.colpart, p.colpart_accumulate = colp.data_ptr(), 0
+        L.plb_set_attn_bwd_fused(form)
+        try:
+            _lib.profile_enable(True)
+            assert L.plb_launch_attn_bwd(C.byref(p), stream()) == 0
+            torch.cuda.synchronize()
+            prof = _lib.profile_read()
+        finally:
+            _lib.profile_enable(False)
+            L.plb_set_attn_bwd_fused(-1)
+        outs[form] = (dqkv, colp, {k: v["launches"] for k, v in prof.items()})
+    launches = outs[-1][2]
+    assert (launches.get("attn_bwd", 0), launches.get("attn_bwd_dq", 0)) == (int(nf > 0), int(nf < B)), (launches, nf)
+    rows_f = slice(0, nf * S)
+    rows_s = slice(nf * S, B * S)
+    assert torch.equal(outs[-1][0][rows_f], outs[1][0][rows_f]) and torch.equal(outs[-1][0][rows_s], outs[0][0][rows_s])
+    cf, cs = slice(0, nf * QT * 4), slice(nf * QT * 4, B * QT * 4)
+    assert torch.equal(outs[-1][1][cf], outs[1][1][cf]) and torch.equal(outs[-1][1][cs], outs[0][1][cs])
+    ref = torch_attention(qkv, lengths, B, S, NH)[2](dctx)
+    assert rel_l2(outs[-1][0].float(), ref) < 1.5e-2
+    assert torch.allclose(outs[-1][1].double().sum(0), outs[-1][0].double().sum(0), rtol=1e-5, atol=1e-3 * float(ref.abs().max()) * 10)
+
+
+@pytest.mark.parametrize("with_rows", [False, True])
+def test_attention_bwd_fused_writes_the_fp8_image(with_rows):
+    """fp8 calls: the single-kernel form writes the e5m2 image of dQKV itself (alone in a training call whose weight
+    gradients read images: p.dqkv = NULL) — the values as rounded to bf16, times the site's scale — and reports the
+    maximum. A call that needs rows AND image (with_rows) is refused by the fused launcher and taken by the two kernels;
+    the images of the two forms agree wherever their bf16 rows agree bitwise, and within an e5m2 step elsewhere."""
+    L = _lib.lib()
+    B, S, NH = 4, 512, 4
+    H = NH * 64
+    qkv = randbf(B * S, 3 * H, scale=1.0, seed=61)
+    lengths = torch.tensor([512, 512, 400, 77], dtype=torch.int32, device=DEV)
+    p, ctx, lse = attn_args(qkv, lengths, B, S, NH)
+    assert L.plb_launch_attn_fwd(C.byref(p), stream()) == 0
+    dctx = randbf(B * S, H, seed=62)
+    qmask = (torch.arange(S, device=DEV)[None, :] < lengths[:, None]).reshape(B * S, 1)
+    dctx = dctx * qmask.to(dctx.dtype)
+    delta = torch.zeros((B, NH, S), dtype=torch.float32, device=DEV)
+    scale = torch.tensor([512.0], device=DEV)
+    res = {}
+    for form in (1, 0):
+        dqkv = torch.zeros((B * S, 3 * H), dtype=torch.bfloat16, device=DEV)
+        img = torch.full((B * S, 3 * H), 0x7B, dtype=torch.uint8, device=DEV)
+        amax = torch.zeros(64 * 16, device=DEV)
+        p.dctx, p.lddctx, p.delta, p.lddqkv = dctx.data_ptr(), H, delta.data_ptr(), 3 * H
+        p.dqkv = dqkv.data_ptr() if (with_rows or form == 0) else None
+        p.dqkv8, p.lddqkv8, p.dqkv_scale, p.dqkv_amax = img.data_ptr(), 3 * H, scale.data_ptr(), amax.data_ptr()
+        if form == 1 and with_rows:
+            assert L.plb_launch_attn_bwd_fused(C.byref(p), stream()) != 0     # refused: the policy sends it to the two kernels
+            continue
+        L.plb_set_attn_bwd_fused(form)
+        try:
+            assert L.plb_launch_attn_bwd(C.byref(p), stream()) == 0
+            torch.cuda.synchronize()
+        finally:
+            L.plb_set_attn_bwd_fused(-1)
+        res[form] = (dqkv, img.view(torch.float8_e5m2).float() / 512.0, float(amax.max()))
+    if with_rows:
+        return
+    rows, img0, am0 = res[0]
+    _, img1, am1 = res[1]
+    want = (rows.float() * 512.0).clamp(-57344, 57344).to(torch.float8_e5m2).float() / 512.0
+    assert torch.equal(img0, want)                                  # two-kernel form: image of its own bf16 rows
+    assert abs(am0 - float(rows.float().abs().max())) <= 1e-6 * am0
+    # the fused form's values differ from the two-kernel form's by accumulation order (bf16 rounding flips), so its image is
+    # compared as numbers: within the e5m2 step of the reference gradient, and its maximum is the maximum of what it stored
+    ref = torch_attention(qkv, lengths, B, S, NH)[2](dctx)
+    assert rel_l2(img1, ref) < 0.08 and rel_l2(img0, ref) < 0.08   # e5m2: 2 mantissa bits
+    assert abs(am1 - am0) <= 2e-2 * am0
+    kpad = ~(torch.arange(S, device=DEV)[None, :] < lengths[:, None]).reshape(B * S)
+    assert (img1[kpad] == 0).all()
 
 
 @pytest.mark.parametrize("ramp", [0.0, 0.02, 0.5])
