@@ -299,7 +299,8 @@ int plb_profile_read(double* ms, int64_t* launches, double* flops, double* bytes
  *                                 (bench.py --gpus N prints them: RCCL-vs-GEMM contention readable from one line)
  *   plb_set_gemm_nt_tile / plb_set_gemm_nt_prefetch / plb_set_attn_bwd_fused
  *                                 force a tile, a K-loop form or the attention-backward form for the launches that
- *                                 follow (0 / -1 / 0 restore the per-shape policy), tests/test_gpu_kernels.py, tools/ */
+ *                                 follow (0 / -1 / -1 restore the per-shape policy; attention backward: 1 single-kernel
+ *                                 form, 0 two kernels, 2 policy + split by sample), tests/test_gpu_kernels.py, tools/ */
 void plb_debug_skip_piece(int index);
 void plb_debug_ln_fault(int mode, int launches);
 int plb_debug_hb_audit(PlbEngine* e, int32_t on, int32_t break_wait);

@@ -530,15 +530,17 @@ extern "C" int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream) {
 // Two forms of the backward. The two-kernel form (dQ kernel + dK/dV kernel, any S) runs 4 workgroups per CU and packs
 // any grid; the single-kernel form (attn_bwd_fused.hip, S <= 512: five products instead of seven, one exponential pass)
 // needs a whole CU per (batch, head), so it pays only where B x heads fills the 256 CUs in (nearly) whole rounds —
-// measured (profiles/r03_attn_bwd_fused_vs_split.txt, r05_attn_bwd_policy.txt): 16 x 16 heads = exactly one round: 74-78 vs
-// 83 us; 32 x 12 = 1.5 rounds: 143-149 vs 127 us. Policy per call (PLBERT_ATTN_BWD = fused | split | auto, default auto;
-// plb_set_attn_bwd_fused(1 / 0 / -1) likewise):
-//   auto: S in (384, 512] and the last round of B x heads at least 90 % full -> fused; else, if at least one FULL round of
-//         256 items fits and the remainder is at most half a round, the first floor(256 / heads) samples per round take
-//         the fused kernel and the remaining samples the two-kernel form (PLBERT_ATTN_BWD_HYBRID=0 turns this off);
-//         everything else -> two kernels. An fp8 call that needs bf16 rows AND the image -> two kernels.
-static int g_bwd_fused = -2;   // -2: read the environment; -1 auto, 0 split, 1 fused
-extern "C" void plb_set_attn_bwd_fused(int on) { g_bwd_fused = on < 0 ? -1 : (on ? 1 : 0); }
+// measured (profiles/r03_attn_bwd_fused_vs_split.txt, r05_attn_bwd_policy_ab.txt): 16 x 16 heads = exactly one round: 74-78
+// vs 83 us per launch, -0.35 ms per step at config D (bf16; fp8 -0.23); 32 x 12 = 1.5 rounds: 143-149 vs 127 us.
+// Policy per call (PLBERT_ATTN_BWD = fused | split | auto | hybrid, default auto; plb_set_attn_bwd_fused(1 / 0 / -1 / 2)):
+//   auto:   S in (384, 512] and the last round of B x heads at least 90 % full -> fused; everything else -> two kernels.
+//           An fp8 call that needs bf16 rows AND the image -> two kernels.
+//   hybrid: as auto, and a batch with at least one (nearly) full round of whole samples plus a short remainder is split
+//           BY SAMPLE: floor(256 / heads) samples per round to the fused kernel, the rest to the two kernels. Built and
+//           measured in round 5 at config A (21 + 11 samples): +0.26 ms per step in bf16, +0.30 in fp8 — the remainder's
+//           528 short workgroups cost 70 us, not the 44 their share of the full grid suggests. Off; kept for the record.
+static int g_bwd_fused = -2;   // -2: read the environment; -1 auto, 0 split, 1 fused, 2 auto + hybrid
+extern "C" void plb_set_attn_bwd_fused(int on) { g_bwd_fused = on < 0 ? -1 : (on > 2 ? 1 : on); }
 static int launch_attn_bwd_split(const PlbAttn* p, hipStream_t stream) {
   dim3 grid(((p->S + 127) / 128) * p->NH * p->B), block(256);
   // algorithmic work of the backward = 4 products (dP, dQ, dV, dK); the S recomputation in each
@@ -572,12 +574,11 @@ static PlbAttn attn_samples(const PlbAttn* p, int b0, int nb) {
 
 extern "C" int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream) {
   if (check_attn(p) || p->lddctx % 8 || p->lddqkv % 8 || (!p->dqkv && !p->dqkv8) || (p->dqkv8 && (!p->dqkv_scale || p->lddqkv8 % 8))) return 1;
-  static int hybrid_on = -1;
   if (g_bwd_fused == -2) {
     const char* e = getenv("PLBERT_ATTN_BWD");
-    g_bwd_fused = (e && !strcmp(e, "fused")) ? 1 : (e && !strcmp(e, "split")) ? 0 : -1;
+    g_bwd_fused = (e && !strcmp(e, "fused")) ? 1 : (e && !strcmp(e, "split")) ? 0 : (e && !strcmp(e, "hybrid")) ? 2 : -1;
   }
-  if (hybrid_on < 0) { const char* e = getenv("PLBERT_ATTN_BWD_HYBRID"); hybrid_on = !(e && !strcmp(e, "0")); }
+  const bool hybrid_on = g_bwd_fused == 2;
   const bool can_fuse = p->S <= 512 && !(p->dqkv && p->dqkv8);
   if (!can_fuse || g_bwd_fused == 0) return launch_attn_bwd_split(p, stream);
   if (g_bwd_fused == 1) return plb_launch_attn_bwd_fused(p, stream);

@@ -237,12 +237,14 @@ def test_attention_race_screen(bwd_form):
             assert all(torch.equal(a, b) for a, b in zip(got, first))
 
 
-@pytest.mark.parametrize("B,NH,nf", [(16, 16, 16), (32, 12, 21), (8, 12, 0), (22, 12, 21)])
-def test_attention_bwd_policy_and_hybrid_split(B, NH, nf):
-    """The per-shape policy (attn.hip: plb_launch_attn_bwd); nf = samples the single-kernel form must take. B x heads that
-    fills the CUs in whole rounds takes it entirely (16 x 16 = 256 items = one round); a batch with at least one (nearly)
-    full round of whole samples and a short remainder is SPLIT BY SAMPLE between the two forms (32 x 12: 21 samples = 252
-    items fused, 11 two-kernel; 22 x 12: 21 + 1); small grids take the two kernels (8 x 12 = 96 items). Whatever the policy picks must equal the forced two-kernel result on the samples each form handled —
+@pytest.mark.parametrize("B,NH,policy,nf", [(16, 16, -1, 16), (32, 12, -1, 0), (8, 12, -1, 0), (32, 12, 2, 21), (22, 12, 2, 21),
+                                             (8, 12, 2, 0)])
+def test_attention_bwd_policy_and_hybrid_split(B, NH, policy, nf):
+    """The per-shape policy (attn.hip: plb_launch_attn_bwd); nf = samples the single-kernel form must take. Policy -1 (auto,
+    the default): B x heads that fills the CUs in whole rounds takes it entirely (16 x 16 = 256 items = one round),
+    everything else the two kernels. Policy 2 (auto + hybrid; measured slower at config A and off by default): a batch with
+    at least one (nearly) full round of whole samples and a short remainder is SPLIT BY SAMPLE between the two forms (32 x
+    12: 21 samples = 252 items fused, 11 two-kernel; 22 x 12: 21 + 1); small grids take the two kernels (8 x 12 = 96 items). Whatever the policy picks must equal the forced two-kernel result on the samples each form handled —
     the fused rows bitwise equal to a forced-fused call, the others bitwise equal to a forced-split call — including the
     bias-gradient partial rows."""
     L = _lib.lib()
@@ -260,7 +262,7 @@ def test_attention_bwd_policy_and_hybrid_split(B, NH, nf):
     dctx = dctx * qmask.to(dctx.dtype)
     delta = torch.zeros((B, NH, S), dtype=torch.float32, device=DEV)
     outs = {}
-    for form in (1, 0, -1):
+    for form in (1, 0, policy):
         dqkv = torch.full((B * S, 3 * H), 7.0, dtype=torch.bfloat16, device=DEV)
         colp = torch.full((B * QT * 4, 3 * H), 3.0, dtype=torch.float32, device=DEV)
         p.dctx, p.lddctx, p.delta, p.dqkv, p.lddqkv = dctx.data_ptr(), H, delta.data_ptr(), dqkv.data_ptr(), 3 * H
@@ -275,6 +277,7 @@ def test_attention_bwd_policy_and_hybrid_split(B, NH, nf):
             _lib.profile_enable(False)
             L.plb_set_attn_bwd_fused(-1)
         outs[form] = (dqkv, colp, {k: v["launches"] for k, v in prof.items()})
+    outs[-1] = outs[policy]
     launches = outs[-1][2]
     assert (launches.get("attn_bwd", 0), launches.get("attn_bwd_dq", 0)) == (int(nf > 0), int(nf < B)), (launches, nf)
     rows_f = slice(0, nf * S)
