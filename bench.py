@@ -819,6 +819,9 @@ def main():
             "step_loss": round(loss_val, 5),
             "step_mfma_frac_wall": round(flop_per_token * B * S / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "loss_parity": parity,
+            # (rows, of): the post-attention part of the LAST application runs on the masked rows only in a phoneme-only
+            # call (include/plbert.h: plb_last_application_rows) — same loss and gradients, ~5 % of the credited FLOPs not executed
+            "last_application_rows": list(eng.last_application_rows()),
             "ranks_seen": ranks_seen, "comm": comm_info, "staged": staged,
             # in-launch hand-offs of the LayerNorm-in-GEMM kernels that timed out over the whole run: must be 0
             "ln_exchange_timeouts": eng.status()["ln_exchange_timeouts"],

@@ -222,6 +222,14 @@ int plb_poll_status(const PlbEngine* e, int32_t* ln_exchange_timeouts);
  * before plb_adamw_step. (With the engine's own communicator both happen inside plb_loss_fwd_bwd.) */
 int plb_status_export(PlbEngine* e, float* out, void* stream);
 int plb_status_import(PlbEngine* e, const float* summed, void* stream);
+/* A phoneme-only loss call evaluates the part of its LAST shared-layer application that lies behind the attention
+ * (dense + LayerNorm, FFN, LayerNorm) on the masked rows alone, forward and backward: the reference computes every row
+ * and then reads the masked ones (train.py:107-131: pred[b, :len_b][idx_b]), rows only meet inside attention, so the other
+ * rows of that part reach neither the loss nor — their output gradient being exactly zero — any gradient. Same results,
+ * ~5 % less arithmetic at 13 % masked positions. Reports what the last loss call did: rows = token rows that part ran on
+ * (padded to 128), of = the call's padded token count (rows == of: every row — a dual-head call, an fp8 call, more than
+ * half of the positions masked, or PLBERT_PRUNE_LAST=0). */
+int plb_last_application_rows(const PlbEngine* e, int64_t* rows, int64_t* of);
 /* What the last training step exchanged: the number of collectives it issued (8 pieces for the reference's phoneme-only
  * step with overlap on, 1 with overlap off; one more after a dual-head step) and the floats they covered. The reference
  * has no counterpart (DDP's bucket count is internal to torch, train.py:218-221); a caller logs it to see which form of
@@ -311,6 +319,9 @@ int plb_comm_trace_read(PlbEngine* e, int32_t max_pieces, int32_t* n, int64_t* b
 void plb_set_gemm_nt_tile(int tile);
 void plb_set_gemm_nt_prefetch(int on);
 void plb_set_attn_bwd_fused(int on);
+/* 0: every loss call evaluates every row of the last application (plb_last_application_rows), 1: masked rows only where
+ * the call qualifies, -1: PLBERT_PRUNE_LAST's choice (default on). tests/test_gpu_engine.py compares the two. */
+void plb_set_prune_last(int on);
 
 #ifdef __cplusplus
 }

@@ -54,11 +54,11 @@ PUBLIC_SYMBOLS = [
     "plb_last_error", "plb_create", "plb_destroy", "plb_param_layout", "plb_workspace_bytes", "plb_bind",
     "plb_sync_weights", "plb_forward", "plb_pooler", "plb_loss_fwd_bwd", "plb_loss_fwd", "plb_loss_fwd_bwd_dual", "plb_adamw_step",
     "plb_set_fp8", "plb_fp8_state", "plb_fp8_stats", "plb_token_head_steps", "plb_set_token_head_steps", "plb_comm_unique_id", "plb_comm_init", "plb_comm_destroy",
-    "plb_comm_info", "plb_comm_pieces", "plb_status", "plb_status_ex", "plb_poll_status", "plb_status_export", "plb_status_import", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
+    "plb_comm_info", "plb_comm_pieces", "plb_last_application_rows", "plb_status", "plb_status_ex", "plb_poll_status", "plb_status_export", "plb_status_import", "plb_broadcast_params", "plb_set_grad_overlap", "plb_allreduce_grads", "plb_apply_mask",
     "plb_mask_batch", "plb_profile_enable", "plb_profile_num_classes", "plb_profile_class_name", "plb_profile_read",
     # test / tuning hooks (documented as such at the end of the header)
     "plb_debug_skip_piece", "plb_debug_ln_fault", "plb_debug_hb_audit", "plb_debug_hb_report", "plb_comm_trace", "plb_comm_trace_read",
-    "plb_set_gemm_nt_tile", "plb_set_gemm_nt_prefetch", "plb_set_attn_bwd_fused",
+    "plb_set_gemm_nt_tile", "plb_set_gemm_nt_prefetch", "plb_set_attn_bwd_fused", "plb_set_prune_last",
 ]
 
 
@@ -198,6 +198,8 @@ def lib():
     L.plb_poll_status.argtypes = [vp, C.POINTER(i32)]
     L.plb_fp8_stats.restype = C.c_int
     L.plb_fp8_stats.argtypes = [vp, C.POINTER(f32), C.POINTER(f32), vp]
+    L.plb_last_application_rows.restype = C.c_int
+    L.plb_last_application_rows.argtypes = [vp, i64p, i64p]
     L.plb_status_export.restype = C.c_int
     L.plb_status_export.argtypes = [vp, vp, vp]
     L.plb_status_import.restype = C.c_int
@@ -267,6 +269,8 @@ def lib():
     L.plb_launch_attn_bwd.argtypes = [C.POINTER(PlbAttn), vp]
     L.plb_launch_attn_bwd_fused.restype = C.c_int
     L.plb_launch_attn_bwd_fused.argtypes = [C.POINTER(PlbAttn), vp]
+    L.plb_set_prune_last.restype = None
+    L.plb_set_prune_last.argtypes = [C.c_int]
     L.plb_set_attn_bwd_fused.restype = None
     L.plb_set_attn_bwd_fused.argtypes = [C.c_int]
     L.plb_launch_ln_fwd.restype = C.c_int

@@ -47,9 +47,20 @@ class AlbertConfig:
         if self.hidden_size % self.num_attention_heads != 0:
             raise ValueError("hidden_size must be a multiple of num_attention_heads")
         if self.hidden_size // self.num_attention_heads != 64:
-            raise ValueError("the attention kernels are built for head_dim 64")
-        if self.embedding_size % 64 or self.hidden_size % 128 or self.intermediate_size % 128:
-            raise ValueError("embedding_size %64, hidden_size %128 and intermediate_size %128 must be 0")
+            raise ValueError(f"head_dim = hidden_size / num_attention_heads = {self.hidden_size} / {self.num_attention_heads} = "
+                             f"{self.hidden_size // self.num_attention_heads}: the attention kernels (csrc/attn.hip) keep a "
+                             "head's 64 features in one MFMA operand and are built for head_dim 64 only "
+                             "(configs/config.yml: 768 / 12; ALBERT-large: 1024 / 16)")
+        # the same limits plb_create enforces (csrc/engine.cpp), reported here — when the model is constructed, not at its
+        # first launch — with the reason
+        if self.embedding_size % 64 or self.embedding_size > 256:
+            raise ValueError(f"embedding_size={self.embedding_size}: must be a multiple of 64, at most 256 (the embedding "
+                             "LayerNorm kernel holds a row in one wave)")
+        if self.hidden_size % 128 or self.hidden_size > 1024:
+            raise ValueError(f"hidden_size={self.hidden_size}: must be a multiple of 128, at most 1024 (a LayerNorm row spans "
+                             "at most 4 column tiles of the fused GEMM epilogues)")
+        if self.intermediate_size % 128:
+            raise ValueError(f"intermediate_size={self.intermediate_size}: must be a multiple of 128 (GEMM tile width)")
 
     @property
     def head_dim(self):

@@ -256,6 +256,11 @@ struct PlbEngine {
   int64_t o_f8amax = 0, o_f8scale = 0, o_f8deq = 0, o_f8stats = 0;
   int f8n = 0;
   bool infer = false;           // inference-only workspace: one layer of activations, no gradient stash
+  // Last application on the masked rows only (a phoneme-only loss call: nothing but the masked positions' final hidden
+  // states reaches the loss, so behind the attention of application L-1 only those rows are computed): decided by the
+  // forward of a call, read by its backward. pruned_rows = the compact row count (a multiple of 128), 0 = the call was full.
+  int pruned_rows = 0;
+  int64_t last_call_rows[2] = {0, 0};   // token rows the last loss call ran the post-attention part of its last application on | of
   int tok_steps = 0;            // AdamW steps the token head has taken (its own bias correction)
   // data-parallel exchange (plb_comm_*): RCCL communicator, its stream, and the join event of the pieces in flight
   RcclComm comm = nullptr;
@@ -827,8 +832,80 @@ static bool tn8_ok(const PlbEngine* e, int64_t Mtot);
 static bool f8_call(const PlbEngine* e, int64_t Tp, bool train) {
   return e->fp8_on && e->fp8_ready && (!train || e->fp8_bwd_ready) && fp8_shapes_ok(e, Tp);
 }
+// ---- the last application on the masked rows only --------------------------------------------------------------------
+// The reference evaluates every position of every application and then reads the masked positions of the LAST one
+// (train.py:107-131: pred[b, :len_b][idx_b]). Positions exchange information only inside attention (keys / values), so
+// behind the attention of application L-1 nothing a non-masked row computes reaches the loss — forward or backward, where
+// its output gradient is exactly zero. A phoneme-only loss call therefore runs dense + LayerNorm, the FFN and the second
+// LayerNorm of application L-1 on the ~13 % masked rows alone (gathered, padded to 128), and their backward likewise; Q/K/V
+// projection and attention stay on all rows (every key / value is needed), and so does everything below application L-1.
+// Results are those of the full evaluation (each row's arithmetic is unchanged; the weight gradients lose only exact
+// zeros from their sums). Compact GEMMs of ~2,300 rows do not fill one-tile-per-CU grids, so this part runs on the
+// small-shape launches (GEMM + LayerNorm kernels, gelu by act 1 / 2): 168 -> 75 us forward, 164 -> 86 us backward, and the
+// three weight-gradient GEMMs that stack its rows read (L-1) Tp + Mc rows instead of L Tp (measured: profiles/r05_*).
+// Not taken by dual-head calls (the token loss reads every position), fp8 calls and PLBERT_PRUNE_LAST=0.
+struct Prune { const int32_t* rows; int n; int Mc; };
+static int g_prune_last = -1;   // test / tuning hook (plb_set_prune_last): -1 the environment's choice, 0 off, 1 on
+extern "C" void plb_set_prune_last(int on) { g_prune_last = on < 0 ? -1 : (on ? 1 : 0); }
+static bool prune_enabled() {
+  static const bool v = [] { const char* e = getenv("PLBERT_PRUNE_LAST"); return !(e && !strcmp(e, "0")); }();
+  return g_prune_last < 0 ? v : g_prune_last != 0;
+}
+// post-attention part of application L-1 on the compact rows; leaves the final hidden rows in o_hm ([Mc][H]: the head's
+// operand) and, in a training call, the compact activations at the START of application L-1's stash slots — the stacked
+// weight-gradient operands then simply end Tp - Mc rows earlier
+static int last_application_fwd_pruned(PlbEngine* e, const Prune* pr, bool stash, bool calib, const bf16_t* x,
+                                       const bf16_t* ctx_att, int64_t Tp, hipStream_t s) {
+  const int H = e->H, I = e->I, L = e->L, Mc = pr->Mc, n = pr->n;
+  const int64_t sl = stash ? L - 1 : 0;
+  const int64_t Tcap = Tp;   // slots of a call are packed with the call's own padded token count
+  bf16_t* ctx_s = e->at<bf16_t>(e->o_ctx) + sl * Tcap * H;
+  bf16_t* pre1_s = e->at<bf16_t>(e->o_pre1) + sl * Tcap * H;
+  bf16_t* a_s = e->at<bf16_t>(e->o_a) + sl * Tcap * H;
+  bf16_t* u = e->at<bf16_t>(e->o_u) + sl * Tcap * I;
+  bf16_t* gl = e->at<bf16_t>(e->o_g) + sl * Tcap * I;
+  bf16_t* pre2 = e->at<bf16_t>(e->o_pre2) + sl * Tcap * H;
+  // training: compact tensors in their own slots (the backward and the weight gradients read them), the gathered
+  // residual rows in a backward temporary; forward-only: the one set of slots, rotated so that nothing is read and
+  // written by the same launch (ctx_att = the ctx slot: gathered into the pre1 slot, whose sum then goes to the ctx slot)
+  bf16_t* ctxc = stash ? ctx_s : pre1_s;
+  bf16_t* xc = stash ? e->at<bf16_t>(e->o_da) : a_s;
+  bf16_t* pre1c = stash ? pre1_s : ctx_s;
+  bf16_t* ac = stash ? a_s : pre1_s;
+  bf16_t* hm = e->at<bf16_t>(e->o_hm);
+  TRY(plb_launch_gather_rows(ctx_att, H, pr->rows, n, Mc, H, ctxc, H, s));
+  TRY(plb_launch_gather_rows(x, H, pr->rows, n, Mc, H, xc, H, s));
+  PlbGemmNT g;
+  memset(&g, 0, sizeof(g));
+  g.A = ctxc; g.lda = H; g.B = e->wbf(PLB_DENSE_W); g.ldb = H; g.M = Mc; g.N = H; g.K = H; g.Mstore = Mc;
+  g.bias = e->par(PLB_DENSE_B); g.res = xc; g.ldr = H; g.C = pre1c; g.ldc = H;
+  TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+  PlbLayerNorm ln;
+  memset(&ln, 0, sizeof(ln));
+  ln.x = pre1c; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.beta = e->par(PLB_LN1_B); ln.eps = e->c.layer_norm_eps;
+  ln.y = ac; ln.ldy = H; ln.T = Mc; ln.H = H;
+  ln.mean = e->at<float>(e->o_mean1) + sl * Tcap; ln.rstd = e->at<float>(e->o_rstd1) + sl * Tcap;
+  TRY(plb_launch_ln_fwd(&ln, s));
+  if (calib) TRY(plb_launch_amax(ac, 1, (size_t)n, H, H, f8_amax(e, f8_site(e, F8_A, L - 1)), s));
+  memset(&g, 0, sizeof(g));
+  g.A = ac; g.lda = H; g.B = e->wbf(PLB_FFN_W); g.ldb = H; g.M = Mc; g.N = I; g.K = H; g.Mstore = Mc;
+  g.bias = e->par(PLB_FFN_B); g.C = u; g.ldc = I; g.C2 = gl; g.ldc2 = I;
+  TRY(plb_launch_gemm_nt(&g, 1, 0, s));
+  if (calib) TRY(plb_launch_amax(gl, 1, (size_t)n, I, I, f8_amax(e, f8_site(e, F8_G, L - 1)), s));
+  memset(&g, 0, sizeof(g));
+  g.A = gl; g.lda = I; g.B = e->wbf(PLB_FFNO_W); g.ldb = I; g.M = Mc; g.N = H; g.K = I; g.Mstore = Mc;
+  g.bias = e->par(PLB_FFNO_B); g.res = ac; g.ldr = H; g.C = pre2; g.ldc = H;
+  TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+  memset(&ln, 0, sizeof(ln));
+  ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.beta = e->par(PLB_LN2_B); ln.eps = e->c.layer_norm_eps;
+  ln.y = hm; ln.ldy = H; ln.T = Mc; ln.H = H;
+  ln.mean = e->at<float>(e->o_mean2) + sl * Tcap; ln.rstd = e->at<float>(e->o_rstd2) + sl * Tcap;
+  TRY(plb_launch_ln_fwd(&ln, s));
+  return 0;
+}
+
 static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths, int B, int S, bool stash, bf16_t** xout,
-                       hipStream_t s) {
+                       hipStream_t s, const Prune* pr = nullptr) {
   const int E = e->E, H = e->H, I = e->I, L = e->L;
   const int T = B * S;
   const int64_t Tp = rup(T, 128);
@@ -891,11 +968,21 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     PlbAttn at;
     memset(&at, 0, sizeof(at));
     at.qkv = qkv; at.ldqkv = 3 * H; at.lengths = lengths; at.B = B; at.S = S; at.NH = e->NH; at.H = H;
-    at.scale = 0.125f; at.ctx = ctx; at.ldctx = H;
+    // pruned last application: the attention output of ALL rows goes to a buffer of its own (training: a backward temporary
+    // that the attention backward of this application reads again — its slot holds the compact rows), then only the masked
+    // rows continue
+    const bool pruned_layer = pr != nullptr && l == L - 1;
+    bf16_t* const ctx_att = (pruned_layer && stash) ? e->at<bf16_t>(e->o_dy1) : ctx;
+    at.scale = 0.125f; at.ctx = ctx_att; at.ldctx = H;
     at.lse = e->at<float>(e->o_lse) + sl * (int64_t)B * e->NH * S;
     if (f8) { at.ctx8 = c8; at.ldctx8 = H; at.ctx_scale = f8_scale(e, sC); at.ctx_amax = f8_amax(e, sC); }
     TRY(plb_launch_attn_fwd(&at, s));
-    if (calib) TRY(plb_launch_amax(ctx, 1, (size_t)T, H, H, f8_amax(e, sC), s));
+    if (calib) TRY(plb_launch_amax(ctx_att, 1, (size_t)T, H, H, f8_amax(e, sC), s));
+    if (pruned_layer) {
+      if (last_application_fwd_pruned(e, pr, stash, calib, x, ctx_att, Tp, s)) return 1;
+      *xout = e->at<bf16_t>(e->o_hm);
+      break;
+    }
     // dense + residual, LayerNorm
     memset(&g, 0, sizeof(g));
     g.A = ctx; g.lda = H; g.B = e->wbf(PLB_DENSE_W); g.ldb = H; g.M = (int)Tp; g.N = H; g.K = H; g.Mstore = (int)Tp;
@@ -1208,11 +1295,21 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     }
     return 0;
   }
-  bf16_t* xL = nullptr;
-  if (run_encoder(e, masked_ids, lengths, B, S, backward, &xL, s)) return 1;
-
   // ---- masked rows: head GEMM, cross-entropy, head gradients ----------------------------------------
   const int NM = (int)rup(n_masked, 128);
+  // the row list first: a phoneme-only call runs the post-attention part of its LAST application on these rows alone
+  // (last_application_fwd_pruned) when that is less than half of the batch; fp8 calls and dual-head calls run every row
+  Prune pr = {e->at<int32_t>(e->o_rows), n_masked, NM};
+  const bool prune = prune_enabled() && n_masked > 0 && !token_targets && L >= 2 && 2 * (int64_t)NM <= Tp &&
+                     !f8_call(e, Tp, backward);
+  if (n_masked > 0)
+    TRY(plb_launch_ce_prepare(idx_offsets, idx_flat, labels, B, S, e->at<int32_t>(e->o_rows), e->at<int32_t>(e->o_tgt),
+                              e->at<float>(e->o_w), s));
+  if (backward) e->pruned_rows = prune ? NM : 0;
+  e->last_call_rows[0] = prune ? NM : Tp; e->last_call_rows[1] = Tp;
+  bf16_t* xL = nullptr;
+  if (run_encoder(e, masked_ids, lengths, B, S, backward, &xL, s, prune ? &pr : nullptr)) return 1;
+
   int32_t* rows = e->at<int32_t>(e->o_rows);
   int32_t* tgt = e->at<int32_t>(e->o_tgt);
   float* w = e->at<float>(e->o_w);
@@ -1225,10 +1322,9 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
   bf16_t* dy = backward ? e->at<bf16_t>(e->o_dy0) : nullptr;
   bf16_t* dy_other = backward ? e->at<bf16_t>(e->o_dy1) : nullptr;
   PlbGemmNT g;
-  if (backward) HIPTRY(hipMemsetAsync(dy, 0, (size_t)Tp * H * 2, s));
+  if (backward && !prune) HIPTRY(hipMemsetAsync(dy, 0, (size_t)Tp * H * 2, s));
   if (n_masked > 0) {
-    TRY(plb_launch_ce_prepare(idx_offsets, idx_flat, labels, B, S, rows, tgt, w, s));
-    TRY(plb_launch_gather_rows(xL, H, rows, n_masked, NM, H, hm, H, s));
+    if (!prune) TRY(plb_launch_gather_rows(xL, H, rows, n_masked, NM, H, hm, H, s));   // (pruned: xL IS hm, the compact rows)
     memset(&g, 0, sizeof(g));
     g.A = hm; g.lda = H; g.B = e->wbf(PLB_HEAD_W); g.ldb = H; g.M = NM; g.N = NP; g.K = H; g.Mstore = NM;
     g.bias = e->par(PLB_HEAD_B); g.Cf = logm; g.ldcf = 256;
@@ -1242,7 +1338,8 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       g.A = dlog; g.lda = 256; g.B = e->at<bf16_t>(e->o_wpT); g.ldb = 256; g.M = NM; g.N = H; g.K = 256; g.Mstore = NM;
       g.C = dhm; g.ldc = H;
       TRY(plb_launch_gemm_nt(&g, 0, 0, s));
-      TRY(plb_launch_scatter_rows(dhm, H, rows, n_masked, H, dy, H, s));
+      // (pruned: the compact gradient rows dhm ARE the output gradient of the last application's compact part)
+      if (!prune) TRY(plb_launch_scatter_rows(dhm, H, rows, n_masked, H, dy, H, s));
     }
   } else {  // dual-head step on a batch without masked phonemes: phoneme loss 0, its head gets zero gradients
     HIPTRY(hipMemsetAsync(loss, 0, sizeof(float), s));
@@ -1350,6 +1447,77 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     uint8_t* dq8 = e->at<uint8_t>(e->o_dq8) + (int64_t)l * Tp * 3 * H;
     const int sDP = f8_site(e, F8_DP, l), sDU = f8_site(e, F8_DU, l), sDP1 = f8_site(e, F8_DP1, l), sDQ = f8_site(e, F8_DQ, l);
     PlbLayerNorm ln;
+    if (prune && l == L - 1) {
+      // ---- backward of the pruned last application: the compact part (LayerNorm 2, FFN, LayerNorm 1, dense) on the Mc
+      // masked rows — small-shape launches, the forward's compact activations at the start of this application's slots —
+      // then its gradients are scattered back to token rows (zeros elsewhere: that is what the full evaluation computes
+      // there) for the attention backward and the dX GEMM, which run on all rows
+      const int Mc = NM;
+      bf16_t* const dac = e->at<bf16_t>(e->o_da);       // dA of the compact rows, then (full) dpre1 scattered to token rows
+      bf16_t* const dctxc = e->at<bf16_t>(e->o_dy0);    // dCtx of the compact rows (dy is not used by this application)
+      bf16_t* const ctx_att = e->at<bf16_t>(e->o_dy1);  // the forward's attention output of all rows
+      memset(&ln, 0, sizeof(ln));
+      ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.T = Mc; ln.H = H; ln.Tzero = Mc;
+      ln.mean = e->at<float>(e->o_mean2) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd2) + (int64_t)l * Tp;
+      ln.dy = dhm; ln.lddy = H; ln.dx = dpre2; ln.lddx = H;
+      ln.partials = e->at<float>(e->o_part2) + (int64_t)l * prows * 3 * H; ln.nblocks = prows;
+      TRY(plb_launch_ln_bwd(&ln, s));
+      if (calib) TRY(plb_launch_amax(dpre2, 1, (size_t)n_masked, H, H, f8_amax(e, sDP), s));
+      memset(&g, 0, sizeof(g));
+      g.A = dpre2; g.lda = H; g.B = e->at<bf16_t>(e->o_w2T); g.ldb = H; g.M = Mc; g.N = I; g.K = H; g.Mstore = Mc;
+      g.aux = u; g.ldaux = I; g.C = du; g.ldc = I;
+      TRY(plb_launch_gemm_nt(&g, 2, 0, s));   // (the forward of this part kept u itself: act 1)
+      if (calib) TRY(plb_launch_amax(du, 1, (size_t)n_masked, I, I, f8_amax(e, sDU), s));
+      if (du_rows > 0) {   // this application's block of ffn.bias partial rows: its column sums in row 0, zeros below
+        float* blk = e->at<float>(e->o_ducol) + (int64_t)l * du_rows * I;
+        TRY(plb_launch_colsum(du, 1, (size_t)Mc, I, I, blk, I, 0, scratch, 16, s));
+        if (du_rows > 1) HIPTRY(hipMemsetAsync(blk + I, 0, (size_t)(du_rows - 1) * I * 4, s));
+      }
+      memset(&g, 0, sizeof(g));
+      g.A = du; g.lda = I; g.B = e->at<bf16_t>(e->o_w1T); g.ldb = I; g.M = Mc; g.N = H; g.K = I; g.Mstore = Mc;
+      g.res = dpre2; g.ldr = H; g.C = dac; g.ldc = H;
+      TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+      memset(&ln, 0, sizeof(ln));
+      ln.x = pre1; ln.ldx = H; ln.gamma = e->par(PLB_LN1_W); ln.T = Mc; ln.H = H; ln.Tzero = Mc;
+      ln.mean = e->at<float>(e->o_mean1) + (int64_t)l * Tp; ln.rstd = e->at<float>(e->o_rstd1) + (int64_t)l * Tp;
+      ln.dy = dac; ln.lddy = H; ln.dx = dpre1; ln.lddx = H;
+      ln.partials = e->at<float>(e->o_part1) + (int64_t)l * prows * 3 * H; ln.nblocks = prows;
+      TRY(plb_launch_ln_bwd(&ln, s));
+      if (calib) TRY(plb_launch_amax(dpre1, 1, (size_t)n_masked, H, H, f8_amax(e, sDP1), s));
+      memset(&g, 0, sizeof(g));
+      g.A = dpre1; g.lda = H; g.B = e->at<bf16_t>(e->o_wdT); g.ldb = H; g.M = Mc; g.N = H; g.K = H; g.Mstore = Mc;
+      g.C = dctxc; g.ldc = H;
+      TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+      // back to token rows: dCtx and dpre1 are zero wherever no masked position sits
+      HIPTRY(hipMemsetAsync(dctx, 0, (size_t)Tp * H * 2, s));
+      TRY(plb_launch_scatter_rows(dctxc, H, rows, n_masked, H, dctx, H, s));
+      HIPTRY(hipMemsetAsync(dac, 0, (size_t)Tp * H * 2, s));   // (dA has been consumed by the LayerNorm backward above)
+      TRY(plb_launch_scatter_rows(dpre1, H, rows, n_masked, H, dac, H, s));
+      PlbAttn at;
+      memset(&at, 0, sizeof(at));
+      at.qkv = qkv; at.ldqkv = 3 * H; at.lengths = lengths; at.B = B; at.S = S; at.NH = e->NH; at.H = H; at.scale = 0.125f;
+      at.ctx = ctx_att; at.ldctx = H; at.lse = e->at<float>(e->o_lse) + (int64_t)l * B * e->NH * S;
+      at.dctx = dctx; at.lddctx = H; at.delta = e->at<float>(e->o_delta); at.dqkv = dqkv; at.lddqkv = 3 * H;
+      at.colpart = e->at<float>(e->o_qkvcol) + (int64_t)l * (B * ((S + 127) / 128) * 4) * 3 * H; at.colpart_accumulate = 0;
+      TRY(plb_launch_attn_bwd(&at, s));
+      if (Tp > T) HIPTRY(hipMemsetAsync(dqkv + (int64_t)T * 3 * H, 0, (size_t)(Tp - T) * 3 * H * 2, s));
+      if (calib) TRY(plb_launch_amax(dqkv, 1, (size_t)T, 3 * H, 3 * H, f8_amax(e, sDQ), s));
+      // dX = dQKV · Wqkv + dpre1 (token rows), with the LayerNorm-2 backward of application L-2 in the epilogue where fused
+      memset(&g, 0, sizeof(g));
+      g.A = dqkv; g.lda = 3 * H; g.B = e->at<bf16_t>(e->o_wqkvT); g.ldb = 3 * H; g.M = (int)Tp; g.N = H; g.K = 3 * H;
+      g.Mstore = (int)Tp; g.res = dac; g.ldr = H; g.C = dy_other; g.ldc = H;
+      if (fuse_b) {
+        g.C = e->at<bf16_t>(e->o_dpre2) + (int64_t)(l - 1) * Tp * H;
+        g.aux = e->at<bf16_t>(e->o_pre2) + (int64_t)(l - 1) * Tp * H; g.ldaux = H;
+        g.colpart = e->at<float>(e->o_part2) + (int64_t)(l - 1) * prows * 3 * H;
+        ln_fields(e, &g, e->par(PLB_LN2_W), nullptr, e->at<float>(e->o_mean2) + (int64_t)(l - 1) * Tp, e->at<float>(e->o_rstd2) + (int64_t)(l - 1) * Tp);
+        TRY(plb_launch_gemm_nt_ln(&g, 6, s));
+      } else {
+        TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+      }
+      bf16_t* tmp = dy; dy = dy_other; dy_other = tmp;
+      continue;
+    }
     if (!(fuse_b && l != L - 1)) {  // fused form: the dX GEMM of application l+1 wrote dpre2 of this one (see below)
       memset(&ln, 0, sizeof(ln));
       ln.x = pre2; ln.ldx = H; ln.gamma = e->par(PLB_LN2_W); ln.T = T; ln.H = H; ln.Tzero = (int)Tp;
@@ -1469,6 +1637,9 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   const int T = B * S;
   const int64_t Tp = rup(T, 128);
   const int64_t Mtot = (int64_t)L * Tp;
+  // stacked rows of the operands whose last application ran on its masked rows only (ffn.weight, ffn_output.weight,
+  // dense.weight: their slots of application L-1 hold Mc compact rows); the Q/K/V weights' operands are always full
+  const int64_t Mtot_c = e->pruned_rows ? (int64_t)(L - 1) * Tp + e->pruned_rows : Mtot;
   PlbGemmNT g;
   // side stream -------------------------------------------------------------------------------------------------------
   // (HB_R / HB_W: the happens-before audit's view of each launch — what it reads that another stream wrote, what it
@@ -1515,8 +1686,8 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
     HB_R(s2, e->at<float>(e->o_ducol), (int64_t)L * du_rows * I * 4, "dU column-sum partial rows");
     TRY(plb_launch_colsum(e->at<float>(e->o_ducol), 0, (size_t)L * du_rows, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 16, s2));
   } else {
-    HB_R(s2, e->at<bf16_t>(e->o_du), Mtot * I * 2, "dU of every application");
-    TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 64, s2));
+    HB_R(s2, e->at<bf16_t>(e->o_du), Mtot_c * I * 2, "dU of every application");
+    TRY(plb_launch_colsum(e->at<bf16_t>(e->o_du), 1, (size_t)Mtot_c, I, I, e->grd(PLB_FFN_B), I, 0, scratch2, 64, s2));
   }
   // LayerNorm-backward partials [L*blocks][3H]: dgamma | dbeta | column sums of dx. (Summing the L applications into
   // one image inside the kernel — PlbLayerNorm.accumulate — was measured: the read-modify-write costs the main stream
@@ -1546,15 +1717,15 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   if (ov && reduce_piece(e, e->poff[PLB_Q_W], e->poff[PLB_Q_B], s)) return 1;
   HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_FFN_W), (int64_t)I * H * 4, "ffn.weight gradient");
   if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_du8), e->at<uint8_t>(e->o_a8), Mtot, I, H, F8_DU, F8_A, e->grd(PLB_FFN_W), s)
-         : weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot, I, H, e->grd(PLB_FFN_W), s)) return 1;
+         : weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot_c, I, H, e->grd(PLB_FFN_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_FFN_W], e->poff[PLB_FFN_B], s)) return 1;
   HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_FFNO_W), (int64_t)I * H * 4, "ffn_output.weight gradient");
   if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp8), e->at<uint8_t>(e->o_g8), Mtot, H, I, F8_DP, F8_G, e->grd(PLB_FFNO_W), s)
-         : weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot, H, I, e->grd(PLB_FFNO_W), s)) return 1;
+         : weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot_c, H, I, e->grd(PLB_FFNO_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_FFNO_W], e->poff[PLB_FFNO_B], s)) return 1;
   HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_DENSE_W), (int64_t)H * H * 4, "dense.weight gradient");
   if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp18), e->at<uint8_t>(e->o_c8), Mtot, H, H, F8_DP1, F8_C, e->grd(PLB_DENSE_W), s)
-         : weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot, H, H, e->grd(PLB_DENSE_W), s)) return 1;
+         : weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot_c, H, H, e->grd(PLB_DENSE_W), s)) return 1;
   if (ov) {
     if (s2 != s) HIPTRY(ev_wait(e, s, e->ev_join));
     if (reduce_piece(e, 0, e->poff[PLB_Q_W], s)) return 1;                    // embeddings, map-in, LN2
@@ -1760,6 +1931,13 @@ extern "C" int plb_comm_trace_read(PlbEngine* e, int32_t max_pieces, int32_t* n,
     if (done_ms) HIPTRY(hipEventElapsedTime(&done_ms[*n], e->tr_call0, t.done));
     *n += 1;
   }
+  return 0;
+}
+
+extern "C" int plb_last_application_rows(const PlbEngine* e, int64_t* rows, int64_t* of) {
+  if (!e) return fail("plb_last_application_rows: null engine");
+  if (rows) *rows = e->last_call_rows[0];
+  if (of) *of = e->last_call_rows[1];
   return 0;
 }
 

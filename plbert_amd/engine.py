@@ -253,6 +253,13 @@ class HipEngine:
                 "pieces": [{"range": [int(a[i]), int(b[i])], "released_ms": round(r[i], 4), "done_ms": round(d[i], 4)}
                            for i in range(n.value)]}
 
+    def last_application_rows(self):
+        """(rows, of): token rows the last loss call ran the post-attention part of its last application on, of the
+        call's padded token count (plb_last_application_rows)."""
+        r, o = C.c_int64(), C.c_int64()
+        _lib.check(self.L.plb_last_application_rows(self.handle, C.byref(r), C.byref(o)), "plb_last_application_rows")
+        return int(r.value), int(o.value)
+
     def comm_pieces(self):
         """(collectives, floats) of the last step's gradient exchange."""
         n, f = C.c_int32(), C.c_int64()

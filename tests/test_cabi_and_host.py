@@ -101,6 +101,15 @@ dataset_params:
     cfg.check_supported()
     with pytest.raises(ValueError):
         plbert_amd.AlbertConfig(vocab_size=188, hidden_size=768, num_attention_heads=12, hidden_act="gelu").check_supported()
+    # shapes the engine has no kernels for are refused when the model is CONSTRUCTED (AlbertModel / HipEngine call
+    # check_supported), with the reason in the message — not at the first launch
+    for kw, word in ((dict(hidden_size=768, num_attention_heads=8), "head_dim"), (dict(hidden_size=2048, num_attention_heads=32), "1024"),
+                     (dict(hidden_size=768, num_attention_heads=12, embedding_size=512), "embedding_size"),
+                     (dict(hidden_size=768, num_attention_heads=12, intermediate_size=2000), "intermediate_size")):
+        with pytest.raises(ValueError, match=word):
+            plbert_amd.AlbertConfig(vocab_size=188, **kw).check_supported()
+        with pytest.raises(ValueError, match=word):
+            plbert_amd.AlbertModel(plbert_amd.AlbertConfig(vocab_size=188, **kw))
 
 
 def test_validate_batch_rejects_bad_inputs():

@@ -152,6 +152,48 @@ def test_real_model_against_reference_probes(name, steps):
     assert eng.status()["ln_exchange_timeouts"] == 0
 
 
+@pytest.mark.parametrize("name", ["real_s128_b8", "real_s512_b2_ragged", "real_h1024_s256_b4"])
+def test_last_application_on_masked_rows_only_equals_the_full_evaluation(name):
+    """A phoneme-only loss call evaluates what lies behind the attention of its LAST application on the masked rows alone
+    (include/plbert.h: plb_last_application_rows): those are the only rows of that part the loss reads (train.py:107-131) and
+    the only ones with a non-zero output gradient. Against the same call with every row evaluated (plb_set_prune_last(0)):
+    the loss agrees to fp32 rounding of the same row arithmetic through differently tiled GEMMs, every gradient tensor to
+    1e-3 relative (the sums lose exact zeros and are grouped differently), and the 3-step AdamW trajectories agree; the
+    validation call (plb_loss_fwd) gives the training call's loss bit for bit in both modes."""
+    from plbert_amd import _lib
+    g = load_golden(name)
+    L = _lib.lib()
+    masked, labels, lens, off, flat, n = _step_inputs(g)
+    out = {}
+    try:
+        for mode in (0, 1):
+            L.plb_set_prune_last(mode)
+            eng, ocfg, pcfg, sd = _engine(g)
+            l_val = float(eng.loss_fwd(masked, labels, lens, off, flat, n).item())
+            losses = []
+            for step in range(1, 4):
+                loss = eng.loss_fwd_bwd(masked, labels, lens, off, flat, n)
+                if step == 1:
+                    torch.cuda.synchronize()
+                    grads = eng.grads[: eng.trainable].clone()
+                    rows = eng.last_application_rows()
+                losses.append(float(loss.item()))
+                eng.adamw_step(step, lr=7e-5)
+            assert l_val == losses[0]
+            out[mode] = (losses, grads, rows, eng)
+    finally:
+        L.plb_set_prune_last(-1)
+    (lf, gf, rf, ef), (lp, gp, rp, ep) = out[0], out[1]
+    assert rf[0] == rf[1] and rp[0] < rp[1] // 2 + 1 and rp[0] % 128 == 0, (rf, rp)     # the second run really was pruned
+    assert np.allclose(lp, lf, rtol=2e-5), (lp, lf)
+    for k, (o, sz, shp) in ep.layout.items():
+        if o + sz > ep.trainable or k == KEY_BIAS:
+            continue
+        a, b = gp[o:o + sz], gf[o:o + sz]
+        assert rel_l2(a, b) < 1e-3, (k, rel_l2(a, b))
+    assert abs(lp[0] - float(g["loss"])) / float(g["loss"]) < 1e-3
+
+
 def test_against_oracle_random_shapes():
     """Oracle parity on shapes the goldens do not hold: ragged batch, S not a multiple of 64."""
     ocfg = onp.Config(embedding_size=128, hidden_size=256, num_attention_heads=4, intermediate_size=512,
