@@ -157,9 +157,12 @@ def test_last_application_on_masked_rows_only_equals_the_full_evaluation(name):
     """A phoneme-only loss call evaluates what lies behind the attention of its LAST application on the masked rows alone
     (include/plbert.h: plb_last_application_rows): those are the only rows of that part the loss reads (train.py:107-131) and
     the only ones with a non-zero output gradient. Against the same call with every row evaluated (plb_set_prune_last(0)):
-    the loss agrees to fp32 rounding of the same row arithmetic through differently tiled GEMMs, every gradient tensor to
-    1e-3 relative (the sums lose exact zeros and are grouped differently), and the 3-step AdamW trajectories agree; the
-    validation call (plb_loss_fwd) gives the training call's loss bit for bit in both modes."""
+    the two are different bf16 evaluations of the same function (the compact part runs GEMM + LayerNorm kernels and gelu from
+    the stored pre-activation where the full evaluation runs the fused epilogues), so they agree as two bf16 runs do: loss
+    1e-4 (the reference bar is 1e-3), every gradient tensor 1.5e-2 relative L2 (against the reference: 4e-2); the AdamW
+    trajectories stay within the 1e-3 the reference comparison allows — after an update they are two equally valid runs, not one: Adam turns the rounding
+    noise of (near-)zero gradient coordinates into +-lr steps, differently in the two; the validation call (plb_loss_fwd)
+    gives the training call's loss bit for bit in both modes."""
     from plbert_amd import _lib
     g = load_golden(name)
     L = _lib.lib()
@@ -185,12 +188,12 @@ def test_last_application_on_masked_rows_only_equals_the_full_evaluation(name):
         L.plb_set_prune_last(-1)
     (lf, gf, rf, ef), (lp, gp, rp, ep) = out[0], out[1]
     assert rf[0] == rf[1] and rp[0] < rp[1] // 2 + 1 and rp[0] % 128 == 0, (rf, rp)     # the second run really was pruned
-    assert np.allclose(lp, lf, rtol=2e-5), (lp, lf)
+    assert abs(lp[0] - lf[0]) <= 1e-4 * lf[0] and np.allclose(lp, lf, rtol=1e-3), (lp, lf)
     for k, (o, sz, shp) in ep.layout.items():
         if o + sz > ep.trainable or k == KEY_BIAS:
             continue
         a, b = gp[o:o + sz], gf[o:o + sz]
-        assert rel_l2(a, b) < 1e-3, (k, rel_l2(a, b))
+        assert rel_l2(a, b) < 1.5e-2, (k, rel_l2(a, b))
     assert abs(lp[0] - float(g["loss"])) / float(g["loss"]) < 1e-3
 
 
@@ -264,7 +267,12 @@ def test_large_config_hidden1024_against_oracle(B, monkeypatch):
     finally:
         _lib.profile_enable(False)
     fused = prof.get("gemm_nt_lnfwd", {}).get("launches", 0) + prof.get("gemm_nt_lnbwd", {}).get("launches", 0)
-    assert fused == (6 + 5 if B == 4 else 0), prof.keys()   # 3 layers: 2 forward + 2 backward per layer, minus the last LN2 backward
+    # 3 layers: 2 forward + 2 backward fused launches per layer, minus the last LN2 backward (its output gradient comes from
+    # the head) = 6 + 5; with the last application's post-attention part on the masked rows only (small-shape launches:
+    # plb_last_application_rows) its 2 forward launches and its LayerNorm-1 backward are not fused ones: 4 + 4
+    rows, of = eng.last_application_rows()
+    assert rows < of                                          # ~13 % masked positions: the call was pruned
+    assert fused == (4 + 4 if B == 4 else 0), prof.keys()
     assert abs(float(loss.item()) - float(loss_ref)) / float(loss_ref) < 1e-3
     for k, want in G.items():
         _grad_close(eng, k, want, 4e-2)
