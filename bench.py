@@ -206,6 +206,11 @@ def pmc_traffic(cls):
     return {"bytes": round(fetch + write), "fetch": round(fetch), "write": round(write), "launches_sampled": launches}
 
 
+def note(msg):
+    """Progress on stderr (the JSON line is the only thing on stdout): a run of several minutes must not look hung."""
+    print(f"bench.py [{time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def secondary_lines():
     """BASELINE.json configs[3] and configs[4] (and both together) beside the headline: short runs of this script as fresh child processes,
     one after the other (a child is a new process with its own HIP context; nothing is exec'ed over this one). Each
@@ -218,6 +223,7 @@ def secondary_lines():
     for key, extra in (("large", ["--model", "large"]), ("fp8", ["--dtype", "fp8"]), ("large_fp8", ["--model", "large", "--dtype", "fp8"])):
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "8", "--no-cpu-baseline",
                "--no-traffic", "--no-staged", "--no-secondary", *extra]
+        note(f"secondary.{key}")
         try:
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240, text=True)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -360,12 +366,18 @@ def pipeline_lines():
         for n in PIPELINE_WORKERS:
             cmd = [sys.executable, os.path.abspath(__file__), "--pipeline-workers", str(n), "--dtype", dtype, "--steps", "100",
                    "--warmup", "10"]
-            try:
-                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=180, text=True)
-                line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-                rows.append(json.loads(line[-1]) if r.returncode == 0 and line else {"workers": n, "error": f"rc {r.returncode}"})
-            except Exception as ex:
-                rows.append({"workers": n, "error": repr(ex)})
+            note(f"secondary.pipeline {dtype} workers {n}")
+            # the child's stdout is a FILE, not a pipe: the DataLoader's worker processes inherit it and outlive the child by
+            # a few seconds (it leaves through os._exit) — a pipe would not reach end-of-file until the last of them is gone
+            import tempfile
+            with tempfile.TemporaryFile(mode="w+") as f:
+                try:
+                    r = subprocess.run(cmd, stdout=f, stderr=subprocess.DEVNULL, stdin=subprocess.DEVNULL, timeout=180)
+                    f.seek(0)
+                    line = [ln for ln in f.read().splitlines() if ln.startswith("{")]
+                    rows.append(json.loads(line[-1]) if r.returncode == 0 and line else {"workers": n, "error": f"rc {r.returncode}"})
+                except Exception as ex:
+                    rows.append({"workers": n, "error": repr(ex)})
         ok = [r["workers"] for r in rows if r.get("ratio_to_resident", 0) >= 0.97]
         out[dtype] = {"runs": rows, "min_workers_for_0.97_of_resident": min(ok) if ok else None}
     return out
@@ -641,6 +653,8 @@ def main():
             overlap_choice = args.overlap == "on"
         eng.set_grad_overlap(overlap_choice)
         comm_info["overlap"] = overlap_choice
+    if rank == 0:
+        note("timed region")
     run_steps(args.warmup)
     dt, loss = timed(run_steps, args.steps)
     loss_val = float(loss.item())
@@ -787,6 +801,7 @@ def main():
 
     if roofline is not None and world == 1 and not dist.is_initialized() and not args.no_traffic and not args.num_tokens \
             and args.dtype == "bf16":
+        note("roofline.traffic (two rocprofv3 --pmc child runs)")
         t = pmc_traffic(roofline["kernel"])
         if t is not None:
             roofline["traffic"] = t["bytes"]
@@ -798,6 +813,7 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.num_tokens:
+        note("cpu_baseline")
         cpu = cpu_baseline(args.cpu_seconds)
     secondary = None
     if (rank == 0 and world == 1 and not dist.is_initialized() and not args.no_secondary and args.model == "base"

@@ -110,8 +110,15 @@ class _Sites:
 
 
 def loss_and_grads_fp8(cfg, P, masked_ids, labels, lengths, masked_indices, amax=None, tn8=True, bf16=False,
-                       dtype=np.float64):
+                       dtype=np.float64, prune_last=False):
     """One loss call: (loss, phoneme_pred, grads-by-name, maxima recorded per site).
+
+    prune_last: restates the device's evaluation of the LAST application's post-attention part on the masked rows only
+    (csrc/engine.cpp last_application_fwd_pruned; a phoneme-only call with at most half of the positions masked). That part
+    runs in bf16 even inside an fp8 call — dense, FFN and their dX GEMMs on the bf16 weight copies and un-rounded operands,
+    the pre-activation u stored in bf16 with gelu / gelu' taken from the stored value — while the stacked weight-gradient
+    GEMMs still read 1-byte images of its (compact) rows. Rows without a masked position carry an exactly zero gradient
+    through that part, so evaluating every row here gives the device's sums.
 
     amax=None: the calibration call — plain arithmetic (== albert_np.loss_and_grads when bf16=False).  amax = the dict a
     previous call returned: the fp8 call.  bf16=True: bfloat16 stores as on the device (module docstring).  Follows
@@ -156,7 +163,10 @@ def loss_and_grads_fp8(cfg, P, masked_ids, labels, lengths, masked_indices, amax
         return (t[:, i * H:(i + 1) * H].reshape(B, S, nh, d).transpose(0, 2, 1, 3) for i in range(3))
 
     layers = []
-    for _ in range(cfg.num_hidden_layers):
+    L = cfg.num_hidden_layers
+    w16 = {k: (round_bf16(v) if bf16 else v) for k, v in (("d", Wd), ("1", W1), ("2", W2))}
+    for li in range(L):
+        cpt = prune_last and li == L - 1                         # the compact part: bf16 launches, also inside an fp8 call
         x8 = Q("X", x)
         qkv = r16(x8.reshape(T, H) @ Wqkv_f.T + bqkv)
         q, k, v = heads(qkv)
@@ -169,18 +179,22 @@ def loss_and_grads_fp8(cfg, P, masked_ids, labels, lengths, masked_indices, amax
         pr = pe / lsum
         ctx = r16(((r16(pe) @ v) / lsum).transpose(0, 2, 1, 3).reshape(B, S, H))   # P rounded for the second product only
         c8 = Q("C", ctx)
-        pre1 = r16(x + (c8 @ Wd_f.T + bd))                                          # the residual is the un-rounded (bf16) x
+        pre1 = r16(x + ((ctx @ w16["d"].T if cpt else c8 @ Wd_f.T) + bd))         # the residual is the un-rounded (bf16) x
         a, ln1 = ref.layer_norm_fwd(pre1, g1, b1, eps)
         a = r16(a)
         a8 = Q("A", a)
-        u = a8 @ W1_f.T + c1                                                        # never stored: gelu and gelu' from the fp32 value
-        gact, dgelu = r16(ref.gelu_new(u)), r16(ref.gelu_new_grad(u))
+        if cpt:   # act 1 / act 2 launches: u is STORED (bf16); gelu from the stored value, gelu' evaluated in the backward epilogue
+            u = r16(a @ w16["1"].T + c1)
+            gact, dgelu = r16(ref.gelu_new(u)), ref.gelu_new_grad(u)
+        else:
+            u = a8 @ W1_f.T + c1                                                    # never stored: gelu and gelu' from the fp32 value
+            gact, dgelu = r16(ref.gelu_new(u)), r16(ref.gelu_new_grad(u))
         g8 = Q("G", gact)
-        pre2 = r16((g8 @ W2_f.T + c2) + a)
+        pre2 = r16(((gact @ w16["2"].T if cpt else g8 @ W2_f.T) + c2) + a)
         y, ln2 = ref.layer_norm_fwd(pre2, g2, b2, eps)
         y = r16(y)
         layers.append(dict(x=x, x8=x8, q=q, k=k, v=v, pr=pr, ctx=ctx, c8=c8, ln1=ln1, a=a, a8=a8, dgelu=dgelu, g=gact, g8=g8,
-                           ln2=ln2))
+                           ln2=ln2, cpt=cpt))
         x = y
     h = x
 
@@ -202,17 +216,17 @@ def loss_and_grads_fp8(cfg, P, masked_ids, labels, lengths, masked_indices, amax
         dp8 = Q("DP", dpre2)
         acc(LAYER + "full_layer_layer_norm.weight", dg2)
         acc(LAYER + "full_layer_layer_norm.bias", db2)
-        du = r16((dp8 @ W2_b) * c["dgelu"])
+        du = r16(((dpre2 @ w16["2"]) if c["cpt"] else (dp8 @ W2_b)) * c["dgelu"])
         du8 = Q("DU", du)
         acc(LAYER + "ffn.bias", du.reshape(T, -1).sum(0))
-        da = r16(du8 @ W1_b + dpre2)
+        da = r16(((du @ w16["1"]) if c["cpt"] else (du8 @ W1_b)) + dpre2)
         dpre1, dg1, db1 = ref.layer_norm_bwd(da, c["ln1"], g1)
         acc(LAYER + "attention.dense.bias", dpre1.reshape(T, H).sum(0))
         dpre1 = r16(dpre1)
         dp18 = Q("DP1", dpre1)
         acc(LAYER + "attention.LayerNorm.weight", dg1)
         acc(LAYER + "attention.LayerNorm.bias", db1)
-        dctx = r16(dp18 @ Wd_b)
+        dctx = r16((dpre1 @ w16["d"]) if c["cpt"] else (dp18 @ Wd_b))
         dO = dctx.reshape(B, S, nh, d).transpose(0, 2, 1, 3)
         O = c["ctx"].reshape(B, S, nh, d).transpose(0, 2, 1, 3)
         pr, q, k, v = c["pr"], c["q"], c["k"], c["v"]

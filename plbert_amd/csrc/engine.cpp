@@ -854,7 +854,7 @@ static bool prune_enabled() {
 // post-attention part of application L-1 on the compact rows; leaves the final hidden rows in o_hm ([Mc][H]: the head's
 // operand) and, in a training call, the compact activations at the START of application L-1's stash slots — the stacked
 // weight-gradient operands then simply end Tp - Mc rows earlier
-static int last_application_fwd_pruned(PlbEngine* e, const Prune* pr, bool stash, bool calib, const bf16_t* x,
+static int last_application_fwd_pruned(PlbEngine* e, const Prune* pr, bool stash, bool calib, bool tn8, const bf16_t* x,
                                        const bf16_t* ctx_att, int64_t Tp, hipStream_t s) {
   const int H = e->H, I = e->I, L = e->L, Mc = pr->Mc, n = pr->n;
   const int64_t sl = stash ? L - 1 : 0;
@@ -901,6 +901,17 @@ static int last_application_fwd_pruned(PlbEngine* e, const Prune* pr, bool stash
   ln.y = hm; ln.ldy = H; ln.T = Mc; ln.H = H;
   ln.mean = e->at<float>(e->o_mean2) + sl * Tcap; ln.rstd = e->at<float>(e->o_rstd2) + sl * Tcap;
   TRY(plb_launch_ln_fwd(&ln, s));
+  if (tn8) {
+    // fp8 training call: this part itself runs in bf16 (2,000 rows: nothing to gain from fp8 operands), but the stacked
+    // weight-gradient GEMMs read 1-byte images of EVERY application: the compact context / a / gelu(u) rows as e4m3 images
+    // at the start of this application's image slots, under the sites' scales, their maxima reported like any other's
+    const void* src[3] = {ctxc, ac, gl}; const int fl[3] = {1, 1, 1};
+    const size_t nel[3] = {(size_t)Mc * H, (size_t)Mc * H, (size_t)Mc * I};
+    const float* sc[3] = {f8_scale(e, f8_site(e, F8_C, L - 1)), f8_scale(e, f8_site(e, F8_A, L - 1)), f8_scale(e, f8_site(e, F8_G, L - 1))};
+    uint8_t* dst[3] = {e->at<uint8_t>(e->o_c8) + sl * Tcap * H, e->at<uint8_t>(e->o_a8) + sl * Tcap * H, e->at<uint8_t>(e->o_g8) + sl * Tcap * I};
+    float* am[3] = {f8_amax(e, f8_site(e, F8_C, L - 1)), f8_amax(e, f8_site(e, F8_A, L - 1)), f8_amax(e, f8_site(e, F8_G, L - 1))};
+    TRY(plb_launch_quantize_multi(3, src, fl, nel, sc, dst, am, s));
+  }
   return 0;
 }
 
@@ -975,11 +986,12 @@ static int run_encoder(PlbEngine* e, const int64_t* ids, const int32_t* lengths,
     bf16_t* const ctx_att = (pruned_layer && stash) ? e->at<bf16_t>(e->o_dy1) : ctx;
     at.scale = 0.125f; at.ctx = ctx_att; at.ldctx = H;
     at.lse = e->at<float>(e->o_lse) + sl * (int64_t)B * e->NH * S;
-    if (f8) { at.ctx8 = c8; at.ldctx8 = H; at.ctx_scale = f8_scale(e, sC); at.ctx_amax = f8_amax(e, sC); }
+    // (pruned: nobody reads the context's image of all rows — the compact rows' image is made with the others, below)
+    if (f8 && !pruned_layer) { at.ctx8 = c8; at.ldctx8 = H; at.ctx_scale = f8_scale(e, sC); at.ctx_amax = f8_amax(e, sC); }
     TRY(plb_launch_attn_fwd(&at, s));
     if (calib) TRY(plb_launch_amax(ctx_att, 1, (size_t)T, H, H, f8_amax(e, sC), s));
     if (pruned_layer) {
-      if (last_application_fwd_pruned(e, pr, stash, calib, x, ctx_att, Tp, s)) return 1;
+      if (last_application_fwd_pruned(e, pr, stash, calib, tn8, x, ctx_att, Tp, s)) return 1;
       *xout = e->at<bf16_t>(e->o_hm);
       break;
     }
@@ -1298,10 +1310,9 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
   // ---- masked rows: head GEMM, cross-entropy, head gradients ----------------------------------------
   const int NM = (int)rup(n_masked, 128);
   // the row list first: a phoneme-only call runs the post-attention part of its LAST application on these rows alone
-  // (last_application_fwd_pruned) when that is less than half of the batch; fp8 calls and dual-head calls run every row
+  // (last_application_fwd_pruned) when that is less than half of the batch; dual-head calls run every row
   Prune pr = {e->at<int32_t>(e->o_rows), n_masked, NM};
-  const bool prune = prune_enabled() && n_masked > 0 && !token_targets && L >= 2 && 2 * (int64_t)NM <= Tp &&
-                     !f8_call(e, Tp, backward);
+  const bool prune = prune_enabled() && n_masked > 0 && !token_targets && L >= 2 && 2 * (int64_t)NM <= Tp;
   if (n_masked > 0)
     TRY(plb_launch_ce_prepare(idx_offsets, idx_flat, labels, B, S, e->at<int32_t>(e->o_rows), e->at<int32_t>(e->o_tgt),
                               e->at<float>(e->o_w), s));
@@ -1484,6 +1495,14 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       ln.partials = e->at<float>(e->o_part1) + (int64_t)l * prows * 3 * H; ln.nblocks = prows;
       TRY(plb_launch_ln_bwd(&ln, s));
       if (calib) TRY(plb_launch_amax(dpre1, 1, (size_t)n_masked, H, H, f8_amax(e, sDP1), s));
+      if (e->tn8_call) {   // fp8 call: the compact gradient rows as e5m2 images for the stacked weight-gradient GEMMs
+        const void* src[3] = {dpre2, du, dpre1}; const int fl[3] = {3, 3, 3};
+        const size_t nel[3] = {(size_t)Mc * H, (size_t)Mc * I, (size_t)Mc * H};
+        const float* sc[3] = {f8_scale(e, sDP), f8_scale(e, sDU), f8_scale(e, sDP1)};
+        uint8_t* dst[3] = {dp8, du8, dp18};
+        float* am[3] = {f8_amax(e, sDP), f8_amax(e, sDU), f8_amax(e, sDP1)};
+        TRY(plb_launch_quantize_multi(3, src, fl, nel, sc, dst, am, s));
+      }
       memset(&g, 0, sizeof(g));
       g.A = dpre1; g.lda = H; g.B = e->at<bf16_t>(e->o_wdT); g.ldb = H; g.M = Mc; g.N = H; g.K = H; g.Mstore = Mc;
       g.C = dctxc; g.ldc = H;
@@ -1499,21 +1518,30 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
       at.ctx = ctx_att; at.ldctx = H; at.lse = e->at<float>(e->o_lse) + (int64_t)l * B * e->NH * S;
       at.dctx = dctx; at.lddctx = H; at.delta = e->at<float>(e->o_delta); at.dqkv = dqkv; at.lddqkv = 3 * H;
       at.colpart = e->at<float>(e->o_qkvcol) + (int64_t)l * (B * ((S + 127) / 128) * 4) * 3 * H; at.colpart_accumulate = 0;
+      if (f8) {   // as in the full evaluation: dQKV's e5m2 image for the fp8 dX GEMM (alone, once the weight gradient reads images too)
+        at.dqkv8 = dq8; at.lddqkv8 = 3 * H; at.dqkv_scale = f8_scale(e, sDQ); at.dqkv_amax = f8_amax(e, sDQ);
+        if (e->tn8_call) at.dqkv = nullptr;
+      }
       TRY(plb_launch_attn_bwd(&at, s));
-      if (Tp > T) HIPTRY(hipMemsetAsync(dqkv + (int64_t)T * 3 * H, 0, (size_t)(Tp - T) * 3 * H * 2, s));
+      if (Tp > T) {
+        if (at.dqkv) HIPTRY(hipMemsetAsync(dqkv + (int64_t)T * 3 * H, 0, (size_t)(Tp - T) * 3 * H * 2, s));
+        if (f8) HIPTRY(hipMemsetAsync(dq8 + (int64_t)T * 3 * H, 0, (size_t)(Tp - T) * 3 * H, s));
+      }
       if (calib) TRY(plb_launch_amax(dqkv, 1, (size_t)T, 3 * H, 3 * H, f8_amax(e, sDQ), s));
       // dX = dQKV · Wqkv + dpre1 (token rows), with the LayerNorm-2 backward of application L-2 in the epilogue where fused
       memset(&g, 0, sizeof(g));
       g.A = dqkv; g.lda = 3 * H; g.B = e->at<bf16_t>(e->o_wqkvT); g.ldb = 3 * H; g.M = (int)Tp; g.N = H; g.K = 3 * H;
       g.Mstore = (int)Tp; g.res = dac; g.ldr = H; g.C = dy_other; g.ldc = H;
+      F8Op oxp = {dq8, e->at<uint8_t>(e->o_wqT8), f8_deq(e, sDQ), f8_deq(e, f8_w(e, F8W_QKVT)), 1};
       if (fuse_b) {
         g.C = e->at<bf16_t>(e->o_dpre2) + (int64_t)(l - 1) * Tp * H;
         g.aux = e->at<bf16_t>(e->o_pre2) + (int64_t)(l - 1) * Tp * H; g.ldaux = H;
         g.colpart = e->at<float>(e->o_part2) + (int64_t)(l - 1) * prows * 3 * H;
         ln_fields(e, &g, e->par(PLB_LN2_W), nullptr, e->at<float>(e->o_mean2) + (int64_t)(l - 1) * Tp, e->at<float>(e->o_rstd2) + (int64_t)(l - 1) * Tp);
-        TRY(plb_launch_gemm_nt_ln(&g, 6, s));
+        if (f8) f8_out(e, &g, e->at<uint8_t>(e->o_dp8) + (int64_t)(l - 1) * Tp * H, H, f8_site(e, F8_DP, l - 1), 1);
+        TRY(gemm_nt_ln_any(&g, 6, f8 ? &oxp : nullptr, s));
       } else {
-        TRY(plb_launch_gemm_nt(&g, 0, 0, s));
+        TRY(gemm_nt_any(&g, 0, f8 ? &oxp : nullptr, s));
       }
       bf16_t* tmp = dy; dy = dy_other; dy_other = tmp;
       continue;
@@ -1716,15 +1744,15 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
          : weight_grad(e, e->at<bf16_t>(e->o_dqkv), 3 * H, 3 * H, e->at<bf16_t>(e->o_x), H, Mtot, 3 * H, H, e->grd(PLB_Q_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_Q_W], e->poff[PLB_Q_B], s)) return 1;
   HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_FFN_W), (int64_t)I * H * 4, "ffn.weight gradient");
-  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_du8), e->at<uint8_t>(e->o_a8), Mtot, I, H, F8_DU, F8_A, e->grd(PLB_FFN_W), s)
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_du8), e->at<uint8_t>(e->o_a8), Mtot_c, I, H, F8_DU, F8_A, e->grd(PLB_FFN_W), s)
          : weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot_c, I, H, e->grd(PLB_FFN_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_FFN_W], e->poff[PLB_FFN_B], s)) return 1;
   HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_FFNO_W), (int64_t)I * H * 4, "ffn_output.weight gradient");
-  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp8), e->at<uint8_t>(e->o_g8), Mtot, H, I, F8_DP, F8_G, e->grd(PLB_FFNO_W), s)
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp8), e->at<uint8_t>(e->o_g8), Mtot_c, H, I, F8_DP, F8_G, e->grd(PLB_FFNO_W), s)
          : weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot_c, H, I, e->grd(PLB_FFNO_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_FFNO_W], e->poff[PLB_FFNO_B], s)) return 1;
   HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_DENSE_W), (int64_t)H * H * 4, "dense.weight gradient");
-  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp18), e->at<uint8_t>(e->o_c8), Mtot, H, H, F8_DP1, F8_C, e->grd(PLB_DENSE_W), s)
+  if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp18), e->at<uint8_t>(e->o_c8), Mtot_c, H, H, F8_DP1, F8_C, e->grd(PLB_DENSE_W), s)
          : weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot_c, H, H, e->grd(PLB_DENSE_W), s)) return 1;
   if (ov) {
     if (s2 != s) HIPTRY(ev_wait(e, s, e->ev_join));

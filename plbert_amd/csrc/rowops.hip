@@ -1025,15 +1025,16 @@ __global__ __launch_bounds__(256) void quantize_multi_kernel(QuantMulti q) {
   float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
     float f[8];
-    if (q.bf16[w]) {
+    if (q.bf16[w] & 1) {   // bit 0: bf16 source (else fp32); bit 1: e5m2 image (else e4m3)
       unpack8(*(const uint4*)((const bf16_t*)q.src[w] + i * 8), f);
     } else {
       const float4 a = *(const float4*)((const float*)q.src[w] + i * 8), b = *(const float4*)((const float*)q.src[w] + i * 8 + 4);
       f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
     }
+    const bool b8 = (q.bf16[w] & 2) != 0;
     uint2 o;
-    o.x = pack_fp8x4(f[0] * s, f[1] * s, f[2] * s, f[3] * s, false);
-    o.y = pack_fp8x4(f[4] * s, f[5] * s, f[6] * s, f[7] * s, false);
+    o.x = pack_fp8x4(f[0] * s, f[1] * s, f[2] * s, f[3] * s, b8);
+    o.y = pack_fp8x4(f[4] * s, f[5] * s, f[6] * s, f[7] * s, b8);
     *(uint2*)(q.dst[w] + i * 8) = o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) m = fmaxf(m, fabsf(f[j]));
@@ -1293,7 +1294,8 @@ extern "C" int plb_launch_quantize(const void* x, int is_bf16, size_t rows, int 
   else hipLaunchKernelGGL((quantize_kernel<false>), dim3(blocks), dim3(256), 0, stream, x, rows, cols, ld, scale, out, ldo, bf8);
   return LAUNCH_OK();
 }
-// n <= 8 contiguous matrices (elements[i] % 8 == 0): dst[i] = e4m3(src[i] * scale[i][0]), amax[i] <- max |src[i]|
+// n <= 8 contiguous matrices (elements[i] % 8 == 0): dst[i] = e4m3(src[i] * scale[i][0]), amax[i] <- max |src[i]|;
+// is_bf16[i]: bit 0 = the source is bf16 (else fp32), bit 1 = the image is e5m2 (gradients) instead of e4m3
 extern "C" int plb_launch_quantize_multi(int n, const void* const* src, const int* is_bf16, const size_t* elements,
                                          const float* const* scale, uint8_t* const* dst, float* const* amax, hipStream_t stream) {
   if (n < 1 || n > 8) return 1;
@@ -1302,7 +1304,7 @@ extern "C" int plb_launch_quantize_multi(int n, const void* const* src, const in
   for (int i = 0; i < n; ++i) {
     if (!src[i] || !dst[i] || !scale[i] || !amax[i] || elements[i] % 8) return 1;
     q.src[i] = src[i]; q.dst[i] = dst[i]; q.scale[i] = scale[i]; q.amax[i] = amax[i]; q.n8[i] = elements[i] / 8; q.bf16[i] = is_bf16[i];
-    bytes += elements[i] * (is_bf16[i] ? 3 : 5);
+    bytes += elements[i] * ((is_bf16[i] & 1) ? 3 : 5);
   }
   ProfScope ps(PLB_K_FP8, stream, 0, (double)bytes);
   hipLaunchKernelGGL(quantize_multi_kernel, dim3(n == 1 ? 1024 : 128, n), dim3(256), 0, stream, q);   // one matrix: the whole chip

@@ -613,9 +613,13 @@ def test_fp8_step_against_the_fp8_restatement(L, B, lens, tn8, monkeypatch):
     l8 = float(eng.loss_fwd_bwd(*args).item())                    # fp8 call under the scales those maxima give
     torch.cuda.synchronize()
     o_l0, _, G0, _ = fp8_np.loss_and_grads_fp8(ocfg, sd, masked, labels, lens, idx)                      # == oracle/albert_np.py
-    o_l16, _, G16, amax = fp8_np.loss_and_grads_fp8(ocfg, sd, masked, labels, lens, idx, bf16=True, dtype=np.float32)
+    o_l16, _, G16, amax = fp8_np.loss_and_grads_fp8(ocfg, sd, masked, labels, lens, idx, bf16=True, dtype=np.float32,
+                                                    prune_last=L >= 2)
+    # (the device evaluates the last application's post-attention part on the masked rows only, in bf16: restated too)
+    pruned = eng.last_application_rows()
+    assert (pruned[0] < pruned[1]) == (L >= 2)
     o_l8, _, G8, _ = fp8_np.loss_and_grads_fp8(ocfg, sd, masked, labels, lens, idx, amax=amax, tn8=tn8, bf16=True,
-                                               dtype=np.float32)
+                                               dtype=np.float32, prune_last=pruned[0] < pruned[1])
     assert abs(l_cal - o_l0) / o_l0 < 1e-3, (l_cal, o_l0)           # the bf16 call against the oracle (north-star bar)
     print(f"\nloss: hip fp8 {l8:.6f}, restated fp8 {o_l8:.6f}; hip bf16 {l_cal:.6f}, restated bf16 {o_l16:.6f}, oracle {o_l0:.6f}")
     lp = "encoder.encoder.albert_layer_groups.0.albert_layers.0."

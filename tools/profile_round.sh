@@ -10,7 +10,7 @@ O=$R/gpurun_out/prof_$tag
 mkdir -p $O
 export TMPDIR=/tmp
 timeout -k 10 600 python bench.py "$@" > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-B="--steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-traffic --no-staged"
+B="--steps 5 --warmup 2 --no-cpu-baseline --no-roofline --no-traffic --no-staged --no-secondary"
 cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py $B "$@" > $O/stats.log 2>&1; echo "stats rc=$?"
 for ctr in FETCH_SIZE WRITE_SIZE; do
   cd /tmp && timeout -k 10 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$ctr -o t -- python3 $R/bench.py $B "$@" > $O/pmc_$ctr.log 2>&1; echo "pmc $ctr rc=$?"
