@@ -284,6 +284,7 @@ struct PlbEngine {
   std::vector<PieceTrace> trace;
   std::vector<hipEvent_t> trace_pool;
   hipEvent_t tr_call0 = nullptr, tr_tail0 = nullptr, tr_tail1 = nullptr;
+  bool tr_tail_valid = false;   // the last traced call reached its tail (a zero-loss call has none)
   // bound buffers
   float *params = nullptr, *grads = nullptr, *m = nullptr, *v = nullptr;
   char* ws = nullptr;
@@ -1280,6 +1281,7 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
     if (e->trace_on) {
       if (!e->tr_call0) { (void)hipEventCreate(&e->tr_call0); (void)hipEventCreate(&e->tr_tail0); (void)hipEventCreate(&e->tr_tail1); }
       (void)hipEventRecord(e->tr_call0, s);
+      e->tr_tail_valid = false;
     }
   }
   if (n_masked == 0 && !token_targets) {  // train.py:129 — zero loss, nothing to back-propagate
@@ -1784,7 +1786,7 @@ static int backward_tail(PlbEngine* e, const int64_t* masked_ids, bf16_t* dy, in
     const hipError_t je = ev_wait(e, s, e->ev_join);
     if (!rc && je != hipSuccess) return fail("plb_loss_fwd_bwd: joining the side stream: %s", hipGetErrorString(je));
   }
-  if (e->trace_on) (void)hipEventRecord(e->tr_tail1, s);
+  if (e->trace_on) { (void)hipEventRecord(e->tr_tail1, s); e->tr_tail_valid = true; }
   if (rc) return rc;
   // from here on the caller's stream may again touch anything in the workspace (the next call's forward will)
   HB_W(s, e->ws, e->ws_bytes, "after the side stream's join (whole workspace)");
@@ -1945,7 +1947,8 @@ extern "C" int plb_comm_trace_read(PlbEngine* e, int32_t max_pieces, int32_t* n,
   if (!e || !n) return fail("plb_comm_trace_read: bad argument");
   *n = 0;
   if (!e->tr_call0) return 0;
-  if (tail_ms) {
+  if (tail_ms) { tail_ms[0] = tail_ms[1] = 0.f; }
+  if (tail_ms && e->tr_tail_valid) {
     HIPTRY(hipEventSynchronize(e->tr_tail1));
     HIPTRY(hipEventElapsedTime(&tail_ms[0], e->tr_call0, e->tr_tail0));
     HIPTRY(hipEventElapsedTime(&tail_ms[1], e->tr_call0, e->tr_tail1));

@@ -30,6 +30,8 @@ for mode in ("bf16", "fp8"):
     torch.cuda.synchronize()
     curves[mode] = np.array([float(x.item()) for x in losses])
     st = tr.engine.status()
+    if mode == "fp8":
+        print("fp8 sites (calls in which values were clamped under the delayed scale, worst overshoot):", tr.engine.fp8_stats(), flush=True)
     print(f"{mode}: ln_exchange_timeouts {st['ln_exchange_timeouts']}, all finite {bool(np.isfinite(curves[mode]).all())}, "
           f"params finite {bool(torch.isfinite(tr.engine.params).all().item())}", flush=True)
     del tr, batches
