@@ -666,7 +666,8 @@ def main():
         # beside begin / end of the weight-gradient tail — a piece that finishes long after tail_ms[1] is what the step
         # waits for; (b) the tail's weight-gradient GEMM time with the exchange running beside it (here) and without
         # (roofline.kernel_ms_per_step, measured after the communicator is gone): RCCL-vs-GEMM CU contention.
-        if overlap_choice:
+        if True:   # traced in the overlapped form whichever form the calibration kept for the timed steps
+            eng.set_grad_overlap(True)
             eng.comm_trace(True)
             run_steps(3)
             tr = eng.comm_trace_read()
@@ -690,6 +691,7 @@ def main():
             tn = [v for k, v in pr.items() if k.startswith("gemm_tn")]
             comm_info["tail_gemm_tn_ms_with_exchange"] = round(max_over_ranks(sum(v["ms"] for v in tn) / 5), 4)
             comm_info["tn_cus"] = int(os.environ.get("PLBERT_TN_CUS", "256"))
+            eng.set_grad_overlap(bool(overlap_choice))
 
     # ---- the same K steps with a fresh batch staged every step (H2D inside the timed region) -------------------
     staged = None
@@ -838,6 +840,9 @@ def main():
             # (rows, of): the post-attention part of the LAST application runs on the masked rows only in a phoneme-only
             # call (include/plbert.h: plb_last_application_rows) — same loss and gradients, ~5 % of the credited FLOPs not executed
             "last_application_rows": list(eng.last_application_rows()),
+            "credited_flops_executed": round(1.0 - 3.0 * (2 * cfg.hidden_size ** 2 + 4 * cfg.hidden_size * cfg.intermediate_size) *
+                                             max(0, eng.last_application_rows()[1] - eng.last_application_rows()[0]) /
+                                             (flop_per_token * B * S), 4),
             "ranks_seen": ranks_seen, "comm": comm_info, "staged": staged,
             # in-launch hand-offs of the LayerNorm-in-GEMM kernels that timed out over the whole run: must be 0
             "ln_exchange_timeouts": eng.status()["ln_exchange_timeouts"],
