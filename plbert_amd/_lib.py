@@ -106,6 +106,8 @@ class PlbAttn(C.Structure):
         ("colpart", C.c_void_p), ("colpart_accumulate", C.c_int),
         ("ctx8", C.c_void_p), ("ldctx8", C.c_int), ("ctx_scale", C.c_void_p), ("ctx_amax", C.c_void_p),
         ("dqkv8", C.c_void_p), ("lddqkv8", C.c_int), ("dqkv_scale", C.c_void_p), ("dqkv_amax", C.c_void_p),
+        ("qoff", C.c_void_p), ("q", C.c_void_p), ("ldq", C.c_int), ("nq_total", C.c_int), ("dq", C.c_void_p), ("lddq", C.c_int),
+        ("dq8", C.c_void_p), ("lddq8", C.c_int),
     ]
 
 

@@ -41,16 +41,22 @@ __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
   len = len < 1 ? 1 : (len > S ? S : len);
   const int q0 = bx * 128 + wave * 32;
   const size_t tok0 = (size_t)b * S;
-  const bf16_t* qbase = p.qkv + hd * 64;
   const bf16_t* kbase = p.qkv + H + hd * 64;
   const bf16_t* vbase = p.qkv + 2 * H + hd * 64;
   const int ld = p.ldqkv;
   const int lq = lane & 31, h = lane >> 5;
+  // compact-query mode (PlbAttn.qoff): this sample's queries are rows [qlo, qlo + Sq) of p.q; outputs by compact row
+  const bool cq = p.qoff != nullptr;
+  const int qlo = cq ? p.qoff[b] : 0;
+  const int Sq = cq ? p.qoff[b + 1] - qlo : S;
+  if (bx * 128 >= Sq) return;   // (wave-uniform, before any barrier: a q tile without a query)
+  const size_t qrow0 = cq ? (size_t)qlo : tok0;   // first query row of the sample in q / ctx
+  const int ldq = cq ? p.ldq : ld;
 
   bf16x8 qf[4];
   {
-    int qr = q0 + lq; qr = qr < S ? qr : S - 1;
-    const bf16_t* qp = qbase + (tok0 + qr) * ld + 8 * h;
+    int qr = q0 + lq; qr = qr < Sq ? qr : Sq - 1;
+    const bf16_t* qp = (cq ? p.q : p.qkv) + hd * 64 + (qrow0 + qr) * ldq + 8 * h;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
   }
@@ -153,16 +159,16 @@ __global__ __launch_bounds__(256, FWD_WAVES) void attn_fwd_kernel(PlbAttn p) {
 #undef KV_STAGE
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
-  if (h == 0 && q0 + lq < S)
-    p.lse[((size_t)b * p.NH + hd) * S + q0 + lq] = -(m_run + __log2f(l_tot)) / sl2;  // see PlbAttn.lse
+  if (h == 0 && q0 + lq < Sq)
+    p.lse[(cq ? (size_t)hd * p.nq_total + qlo : ((size_t)b * p.NH + hd) * S) + q0 + lq] = -(m_run + __log2f(l_tot)) / sl2;  // see PlbAttn.lse
   // all waves are past the last barrier: reuse the staging LDS as per-wave transpose patches
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
-  int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
+  int rows_valid = Sq - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
   // fp8 mode: the e4m3 image of the context rows for the fp8 dense projection and its weight gradient
-  const Out8 o8 = {p.ctx8 ? p.ctx8 + (tok0 + q0) * p.ldctx8 + hd * 64 : nullptr, p.ldctx8, p.ctx8 ? p.ctx_scale[0] : 1.0f, false};
+  const Out8 o8 = {p.ctx8 ? p.ctx8 + (qrow0 + q0) * p.ldctx8 + hd * 64 : nullptr, p.ldctx8, p.ctx8 ? p.ctx_scale[0] : 1.0f, false};
   float amax8 = 0.f;
   if (rows_valid > 0)
-    store_transposed<(ATTN_OUT_NT & 1) != 0>(o0, o1, inv, patch, p.ctx + (tok0 + q0) * p.ldctx + hd * 64, p.ldctx, rows_valid, lane,
+    store_transposed<(ATTN_OUT_NT & 1) != 0>(o0, o1, inv, patch, p.ctx + (qrow0 + q0) * p.ldctx + hd * 64, p.ldctx, rows_valid, lane,
                                              nullptr, false, &o8, &amax8);
   if (p.ctx8 && p.ctx_amax) {
     amax8 = wave_max(amax8);
@@ -191,14 +197,24 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
   const bf16_t* vbase = p.qkv + 2 * H + hd * 64;
   const int ld = p.ldqkv;
   const int lq = lane & 31, h = lane >> 5;
-  int qr = q0 + lq; qr = qr < S ? qr : S - 1;
+  // compact-query mode (PlbAttn.qoff): see the forward
+  const bool cq = p.qoff != nullptr;
+  const int qlo = cq ? p.qoff[b] : 0;
+  const int Sq = cq ? p.qoff[b + 1] - qlo : S;
+  if (bx * 128 >= Sq) {   // a q tile without a query (compact mode only): its bias-gradient partial rows are zeros
+    if (p.colpart && !p.colpart_accumulate) p.colpart[((size_t)(b * QT + bx) * 4 + wave) * (3 * H) + hd * 64 + lane] = 0.f;
+    return;
+  }
+  const size_t qrow0 = cq ? (size_t)qlo : tok0;
+  const int ldq = cq ? p.ldq : ld;
+  int qr = q0 + lq; qr = qr < Sq ? qr : Sq - 1;
 
   bf16x8 qf[4], dof[4];
   float delta;
   {
-    const bf16_t* qp = p.qkv + hd * 64 + (tok0 + qr) * ld + 8 * h;
-    const bf16_t* dop = p.dctx + (tok0 + qr) * p.lddctx + hd * 64 + 8 * h;
-    const bf16_t* op = p.ctx + (tok0 + qr) * p.ldctx + hd * 64 + 8 * h;
+    const bf16_t* qp = (cq ? p.q : p.qkv) + hd * 64 + (qrow0 + qr) * ldq + 8 * h;
+    const bf16_t* dop = p.dctx + (qrow0 + qr) * p.lddctx + hd * 64 + 8 * h;
+    const bf16_t* op = p.ctx + (qrow0 + qr) * p.ldctx + hd * 64 + 8 * h;
     float d = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -210,8 +226,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
     }
     delta = d + __shfl_xor(d, 32, 64);
   }
-  const size_t stat = ((size_t)b * p.NH + hd) * S + qr;
-  if (h == 0 && q0 + lq < S) p.delta[stat] = -delta;   // stored NEGATED: the dK/dV kernel starts its dP accumulators there
+  const size_t stat = (cq ? (size_t)hd * p.nq_total + qlo : ((size_t)b * p.NH + hd) * S) + qr;
+  if (h == 0 && q0 + lq < Sq) p.delta[stat] = -delta;   // stored NEGATED: the dK/dV kernel starts its dP accumulators there
   const float lse2 = p.lse[stat] * (p.scale * LOG2E);  // stored as -LSE in raw-score units (PlbAttn.lse)
   const float sl2 = p.scale * LOG2E;
 
@@ -294,17 +310,22 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(PlbAttn p) {
 #undef DQ_TILE
 #undef KV_STAGE
   bf16_t* patch = &smem[0][0][0] + wave * (32 * 72);
-  int rows_valid = S - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
+  int rows_valid = Sq - q0; rows_valid = rows_valid > 32 ? 32 : rows_valid;
   // bias-gradient partial row of this wave: [(b * QT + q tile) * 4 + wave][3H], columns hd*64.. of the Q block
   float* cp = p.colpart ? p.colpart + ((size_t)(b * QT + bx) * 4 + wave) * (3 * H) + hd * 64 : nullptr;
-  // fp8 mode: the e5m2 image of the gradient rows for the fp8 dX GEMM and the QKV weight gradient (dqkv itself may be off)
-  const Out8 o8 = {p.dqkv8 ? p.dqkv8 + (tok0 + q0) * p.lddqkv8 + hd * 64 : nullptr, p.lddqkv8, p.dqkv8 ? p.dqkv_scale[0] : 1.0f, true};
+  // fp8 mode: the e5m2 image of the gradient rows for the fp8 dX GEMM and the QKV weight gradient (dqkv itself may be off).
+  // Compact-query mode: dQ rows (and their image) go to the compact buffers, not into dqkv's Q block
+  bf16_t* const dq_out = cq ? (p.dq ? p.dq + (qrow0 + q0) * p.lddq + hd * 64 : nullptr)
+                            : (p.dqkv ? p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64 : nullptr);
+  uint8_t* const dq8_out = cq ? (p.dq8 ? p.dq8 + (qrow0 + q0) * p.lddq8 + hd * 64 : nullptr)
+                              : (p.dqkv8 ? p.dqkv8 + (tok0 + q0) * p.lddqkv8 + hd * 64 : nullptr);
+  const Out8 o8 = {dq8_out, cq ? p.lddq8 : p.lddqkv8, dq8_out ? p.dqkv_scale[0] : 1.0f, true};
   float amax8 = 0.f;
   if (rows_valid > 0)
-    store_transposed<(ATTN_OUT_NT & 2) != 0, true>(dq0, dq1, p.scale, patch, p.dqkv ? p.dqkv + (tok0 + q0) * p.lddqkv + hd * 64 : nullptr, p.lddqkv,
+    store_transposed<(ATTN_OUT_NT & 2) != 0, true>(dq0, dq1, p.scale, patch, dq_out, cq ? p.lddq : p.lddqkv,
                      rows_valid, lane, cp, p.colpart_accumulate != 0, &o8, &amax8);
   else if (cp && !p.colpart_accumulate) cp[lane] = 0.f;
-  if (p.dqkv8 && p.dqkv_amax) {
+  if (dq8_out && p.dqkv_amax) {
     amax8 = wave_max(amax8);
     if (lane == 0) atomic_max_abs(p.dqkv_amax, amax8, blockIdx.x * 4 + wave);
   }
@@ -352,12 +373,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   const bool key_ok = mykey < len;
   const float sl2 = p.scale * LOG2E;
 
+  // compact-query mode (PlbAttn.qoff): the queries are rows [qlo, qlo + qrows) of p.q / dctx, statistics [NH][Nq]
+  const bool cq = p.qoff != nullptr;
+  const int qlo = cq ? p.qoff[b] : 0;
+  const int Sq = cq ? p.qoff[b + 1] - qlo : S;    // query rows that exist (clamp bound of the staging)
+  const int qlen = cq ? Sq : len;                 // query rows that count
+  const int ldq = cq ? p.ldq : ld;
   // queries past the length carry exactly zero dO in this model (no loss there), so tiles stop at len
-  const int nqt = (bx * 128 < len) ? ((len + 63) >> 6) : 0;
-  const bf16_t* gq = p.qkv + hd * 64 + tok0 * ld;
-  const bf16_t* gdo = p.dctx + hd * 64 + tok0 * ldo;
-  const float* glse = p.lse + ((size_t)b * p.NH + hd) * S;
-  const float* gdelta = p.delta + ((size_t)b * p.NH + hd) * S;
+  const int nqt = (bx * 128 < len) ? ((qlen + 63) >> 6) : 0;
+  const bf16_t* gq = cq ? p.q + hd * 64 + (size_t)qlo * ldq : p.qkv + hd * 64 + tok0 * ld;
+  const bf16_t* gdo = p.dctx + hd * 64 + (cq ? (size_t)qlo : tok0) * ldo;
+  const float* glse = p.lse + (cq ? (size_t)hd * p.nq_total + qlo : ((size_t)b * p.NH + hd) * S);
+  const float* gdelta = p.delta + (cq ? (size_t)hd * p.nq_total + qlo : ((size_t)b * p.NH + hd) * S);
   // staging: this wave writes rows [16w, 16w+16) of every image, 8 rows (1 KiB) per instruction.
   //  row image  (row_off):  LDS (row, chunk') <- source chunk chunk' ^ ((row >> 1) & 7)
   //  tr image   (tr_off):   LDS 16-byte unit u of 256-byte sub-tile t <- source (row 4(t>>1) + (u>>2), col 32(t&1) + 8(u&3))
@@ -367,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   const int cT = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
   // byte offsets from the tile's first row; the second instruction of an image is 8 rows further (the row image also
   // changes its swizzled column, so it has its own offset; the tr image uses the scalar base + 8 rows)
-  const uint32_t vqA0 = (uint32_t)(rA * ld + cA0) * 2, vqA1 = (uint32_t)((rA + 8) * ld + cA1) * 2, vqT = (uint32_t)(rT * ld + cT) * 2;
+  const uint32_t vqA0 = (uint32_t)(rA * ldq + cA0) * 2, vqA1 = (uint32_t)((rA + 8) * ldq + cA1) * 2, vqT = (uint32_t)(rT * ldq + cT) * 2;
   const uint32_t vdA0 = (uint32_t)(rA * ldo + cA0) * 2, vdA1 = (uint32_t)((rA + 8) * ldo + cA1) * 2, vdT = (uint32_t)(rT * ldo + cT) * 2;
   const uint32_t vst = (uint32_t)lane * 4;
   const uint32_t lds0 = LDS_ADDR(&smem[0][0][0]) + (uint32_t)wave * 2048, ldst = LDS_ADDR(&sstat[0][0][0]);
@@ -375,10 +402,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   do {                                                                                                  \
     const int q0_ = (qt_) * 64;                                                                         \
     const uint32_t l_ = lds0 + (ST) * 32768;                                                            \
-    if (q0_ + 64 <= S) {                                                                                \
-      const char* sq_ = (const char*)(gq + (size_t)q0_ * ld);                                           \
+    if (q0_ + 64 <= Sq) {                                                                               \
+      const char* sq_ = (const char*)(gq + (size_t)q0_ * ldq);                                          \
       const char* sd_ = (const char*)(gdo + (size_t)q0_ * ldo);                                         \
-      const char* sq8_ = sq_ + 16 * ld;                                                                 \
+      const char* sq8_ = sq_ + 16 * ldq;                                                                \
       const char* sd8_ = sd_ + 16 * ldo;                                                                \
       DMA16(sq_, vqA0, l_); DMA16(sq_, vqA1, l_ + 1024);                                                \
       DMA16(sq_, vqT, l_ + 8192); DMA16(sq8_, vqT, l_ + 8192 + 1024);                                   \
@@ -387,15 +414,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
       if (wave == 0) DMA4((const char*)(glse + q0_), vst, ldst + (ST) * 512);                           \
       if (wave == 1) DMA4((const char*)(gdelta + q0_), vst, ldst + (ST) * 512 + 256);                   \
     } else { /* the tile that crosses S: rows are clamped, every lane computes its own offsets */       \
-      const int a0_ = min(q0_ + rA, S - 1), a1_ = min(q0_ + rA + 8, S - 1);                             \
-      const int t0_ = min(q0_ + rT, S - 1), t1_ = min(q0_ + rT + 8, S - 1);                             \
+      const int a0_ = min(q0_ + rA, Sq - 1), a1_ = min(q0_ + rA + 8, Sq - 1);                           \
+      const int t0_ = min(q0_ + rT, Sq - 1), t1_ = min(q0_ + rT + 8, Sq - 1);                           \
       const char* sq_ = (const char*)gq;                                                                \
       const char* sd_ = (const char*)gdo;                                                               \
-      DMA16(sq_, (uint32_t)(a0_ * ld + cA0) * 2, l_); DMA16(sq_, (uint32_t)(a1_ * ld + cA1) * 2, l_ + 1024);                  \
-      DMA16(sq_, (uint32_t)(t0_ * ld + cT) * 2, l_ + 8192); DMA16(sq_, (uint32_t)(t1_ * ld + cT) * 2, l_ + 8192 + 1024);      \
+      DMA16(sq_, (uint32_t)(a0_ * ldq + cA0) * 2, l_); DMA16(sq_, (uint32_t)(a1_ * ldq + cA1) * 2, l_ + 1024);                \
+      DMA16(sq_, (uint32_t)(t0_ * ldq + cT) * 2, l_ + 8192); DMA16(sq_, (uint32_t)(t1_ * ldq + cT) * 2, l_ + 8192 + 1024);    \
       DMA16(sd_, (uint32_t)(a0_ * ldo + cA0) * 2, l_ + 16384); DMA16(sd_, (uint32_t)(a1_ * ldo + cA1) * 2, l_ + 16384 + 1024); \
       DMA16(sd_, (uint32_t)(t0_ * ldo + cT) * 2, l_ + 24576); DMA16(sd_, (uint32_t)(t1_ * ldo + cT) * 2, l_ + 24576 + 1024);   \
-      const uint32_t vs_ = (uint32_t)min(q0_ + lane, S - 1) * 4;                                        \
+      const uint32_t vs_ = (uint32_t)min(q0_ + lane, Sq - 1) * 4;                                       \
       if (wave == 0) DMA4((const char*)glse, vs_, ldst + (ST) * 512);                                   \
       if (wave == 1) DMA4((const char*)gdelta, vs_, ldst + (ST) * 512 + 256);                           \
     }                                                                                                   \
@@ -439,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
     /* s[r] = S[q][key] - LSE: key on the lane, q = qt*64 + qb*32 + (r&3) + 8(r>>2) + 4h */                     \
     _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                            \
       float pr = EXP2(s[r] * sl2);                                                                              \
-      if (MASK) pr = (key_ok && (qt * 64 + (qb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < len)) ? pr : 0.f;       \
+      if (MASK) pr = (key_ok && (qt * 64 + (qb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h < qlen)) ? pr : 0.f;      \
       s[r] = pr;                                                                                                \
     }                                                                                                           \
     _Pragma("unroll") for (int s2 = 0; s2 < 2; ++s2)                                                            \
@@ -466,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(PlbAttn p) {
   do {                                                                                                          \
     const int qt = (qt_);                                                                                       \
     if (qt + 1 < nqt) DKV_STAGE((CUR) ^ 1, qt + 1);                                                             \
-    const bool need_mask = (key0 + 32 > len) || (qt * 64 + 64 > len); /* wave-uniform */                        \
+    const bool need_mask = (key0 + 32 > len) || (qt * 64 + 64 > qlen); /* wave-uniform */                       \
     if (need_mask) { DKV_BLOCK(CUR, true, 0) DKV_BLOCK(CUR, true, 1) }                                          \
     else { DKV_BLOCK(CUR, false, 0) DKV_BLOCK(CUR, false, 1) }                                                  \
     DMA_WAIT();                                                                                                 \
@@ -518,6 +545,7 @@ static int check_attn(const PlbAttn* p) {
 
 extern "C" int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream) {
   if (check_attn(p) || (p->ctx8 && (!p->ctx_scale || p->ldctx8 % 8))) return 1;
+  if (p->qoff && (!p->q || p->ldq % 8 || p->nq_total < 0)) return 1;
   dim3 grid(((p->S + 127) / 128) * p->NH * p->B), block(256);
   const double unit = (double)p->B * p->NH * (double)p->S * p->S * 64.0;
   const double io = 2.0 * p->B * p->S * (double)p->H;
@@ -579,7 +607,8 @@ extern "C" int plb_launch_attn_bwd(const PlbAttn* p, hipStream_t stream) {
     g_bwd_fused = (e && !strcmp(e, "fused")) ? 1 : (e && !strcmp(e, "split")) ? 0 : (e && !strcmp(e, "hybrid")) ? 2 : -1;
   }
   const bool hybrid_on = g_bwd_fused == 2;
-  const bool can_fuse = p->S <= 512 && !(p->dqkv && p->dqkv8);
+  if (p->qoff && (!p->q || p->ldq % 8 || p->nq_total < 0 || (!p->dq && !p->dq8) || (p->dq && p->lddq % 8) || (p->dq8 && p->lddq8 % 8))) return 1;
+  const bool can_fuse = p->S <= 512 && !(p->dqkv && p->dqkv8) && !p->qoff;   // (compact queries: the two-kernel form only)
   if (!can_fuse || g_bwd_fused == 0) return launch_attn_bwd_split(p, stream);
   if (g_bwd_fused == 1) return plb_launch_attn_bwd_fused(p, stream);
   if (p->S <= 384) return launch_attn_bwd_split(p, stream);

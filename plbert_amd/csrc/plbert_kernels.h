@@ -196,6 +196,12 @@ typedef struct {
   // common.h) that collects max |value| for the next step's scale. dqkv may be NULL when dqkv8 is given.
   uint8_t* ctx8; int ldctx8; const float* ctx_scale; float* ctx_amax;
   uint8_t* dqkv8; int lddqkv8; const float* dqkv_scale; float* dqkv_amax;
+  // Compact-query mode (qoff != NULL; two-kernel backward only): the QUERIES of sample b are rows [qoff[b], qoff[b+1]) of
+  // `q` (row stride ldq, head h at columns h*64..) — e.g. the masked positions only — while keys and values stay the S rows
+  // of qkv. ctx / dctx are then indexed by the compact row ([Nq, H], Nq = nq_total = qoff[B]), lse / delta are [NH][Nq],
+  // and dQ goes to dq ([Nq, lddq]; + its e5m2 image dq8 in fp8 mode) instead of dqkv's Q block; dqkv's K and V blocks
+  // (and colpart, row (b * ceil(S/128) + q tile) * 4 + wave as always) are written as in the full form.
+  const int32_t* qoff; const bf16_t* q; int ldq; int nq_total; bf16_t* dq; int lddq; uint8_t* dq8; int lddq8;
 } PlbAttn;
 int plb_launch_attn_fwd(const PlbAttn* p, hipStream_t stream);
 // Default: the two-kernel form, dq (+delta) then dk,dv. plb_set_attn_bwd_fused(1) / PLBERT_ATTN_BWD=fused: ONE kernel for

@@ -342,6 +342,87 @@ def test_attention_bwd_fused_writes_the_fp8_image(with_rows):
     assert (img1[kpad] == 0).all()
 
 
+@pytest.mark.parametrize("B,S,NH,lens,counts", [(3, 512, 2, [512, 300, 512], [70, 33, 140]), (2, 130, 3, None, [5, 0]),
+                                                (4, 512, 12, [512, 449, 130, 512], [64, 128, 1, 200])])
+def test_attention_compact_queries(B, S, NH, lens, counts):
+    """Compact-query mode (PlbAttn.qoff): the queries of a sample are a LIST of rows (the masked positions of the last
+    application, csrc/engine.cpp) gathered into a compact buffer, keys and values stay all S rows. Forward: the compact
+    context rows and statistics equal the full evaluation's rows at those positions BITWISE (a query's arithmetic does not
+    depend on which other queries share its tile). Backward with dO given on the compact rows only: dQ of the compact rows,
+    dK / dV of all rows and the bias-gradient partial rows against torch autograd of the full attention with dO zero
+    elsewhere — and against the full two-kernel form on the scattered dO. Counts include an empty sample, a single query,
+    exactly one tile and more than one tile."""
+    L = _lib.lib()
+    H = NH * 64
+    QT = (S + 127) // 128
+    qkv = randbf(B * S, 3 * H, scale=1.0, seed=71)
+    lengths = torch.tensor(lens, dtype=torch.int32, device=DEV) if lens else None
+    g = torch.Generator().manual_seed(5)
+    rows, off = [], [0]
+    for b, n in enumerate(counts):
+        lim = lens[b] if lens else S
+        pos = torch.randperm(lim, generator=g)[:n].sort().values
+        rows += (pos + b * S).tolist()
+        off.append(off[-1] + n)
+    Nq = off[-1]
+    rows_t = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    qoff = torch.tensor(off, dtype=torch.int32, device=DEV)
+    qc = qkv[rows_t, :H].contiguous()
+    # the full evaluation
+    p, ctx, lse = attn_args(qkv, lengths, B, S, NH)
+    assert L.plb_launch_attn_fwd(C.byref(p), stream()) == 0
+    # compact queries
+    pc, _, _ = attn_args(qkv, lengths, B, S, NH)
+    ctxc = torch.zeros((max(Nq, 1), H), dtype=torch.bfloat16, device=DEV)
+    lsec = torch.zeros((NH, max(Nq, 1)), dtype=torch.float32, device=DEV)
+    pc.ctx, pc.ldctx, pc.lse = ctxc.data_ptr(), H, lsec.data_ptr()
+    pc.qoff, pc.q, pc.ldq, pc.nq_total = qoff.data_ptr(), qc.data_ptr(), H, Nq
+    assert L.plb_launch_attn_fwd(C.byref(pc), stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(ctxc[:Nq], ctx[rows_t])
+    full_lse = lse.reshape(B, NH, S).permute(1, 0, 2).reshape(NH, B * S)[:, rows_t]
+    assert torch.equal(lsec[:, :Nq], full_lse)
+    # backward: dO on the compact rows
+    dctxc = randbf(max(Nq, 1), H, seed=72)
+    dctx_full = torch.zeros((B * S, H), dtype=torch.bfloat16, device=DEV)
+    dctx_full[rows_t] = dctxc[:Nq]
+    out = {}
+    for mode in ("compact", "full"):
+        dqkv = torch.full((B * S, 3 * H), 7.0, dtype=torch.bfloat16, device=DEV)
+        colp = torch.full((B * QT * 4, 3 * H), 3.0, dtype=torch.float32, device=DEV)
+        q = pc if mode == "compact" else p
+        if mode == "compact":
+            delta = torch.zeros((NH, max(Nq, 1)), dtype=torch.float32, device=DEV)
+            dqc = torch.full((max(Nq, 1), H), 5.0, dtype=torch.bfloat16, device=DEV)
+            q.dctx, q.lddctx, q.dq, q.lddq = dctxc.data_ptr(), H, dqc.data_ptr(), H
+        else:
+            delta = torch.zeros((B, NH, S), dtype=torch.float32, device=DEV)
+            q.dctx, q.lddctx = dctx_full.data_ptr(), H
+        q.delta, q.dqkv, q.lddqkv, q.colpart, q.colpart_accumulate = delta.data_ptr(), dqkv.data_ptr(), 3 * H, colp.data_ptr(), 0
+        L.plb_set_attn_bwd_fused(0)
+        try:
+            assert L.plb_launch_attn_bwd(C.byref(q), stream()) == 0
+            torch.cuda.synchronize()
+        finally:
+            L.plb_set_attn_bwd_fused(-1)
+        out[mode] = (dqkv, colp, dqc if mode == "compact" else None)
+    ref = torch_attention(qkv, lengths, B, S, NH)[2](dctx_full)
+    dq_c, (dqkv_c, colp_c, dqc) = None, out["compact"]
+    dqkv_f, colp_f, _ = out["full"]
+    # dK, dV of every row: the same products, but the MFMA sums group the non-zero terms differently when the zero rows
+    # between them are gone: equal to fp32 summation noise seen through bf16 rounding, not bitwise
+    if Nq:
+        assert rel_l2(dqkv_c[:, H:].float(), dqkv_f[:, H:].float()) < 4e-3
+    assert (dqkv_c[:, :H] == 7.0).all()                                  # the Q block of dqkv is not touched in compact mode
+    assert torch.equal(dqc[:Nq], dqkv_f[rows_t, :H])                     # dQ of the compact rows = the full form's rows
+    if Nq:
+        assert rel_l2(dqc[:Nq].float(), ref[rows_t, :H]) < 1.5e-2
+        assert rel_l2(dqkv_c[:, H:].float(), ref[:, H:]) < 1.5e-2
+    # bias-gradient partial rows: K / V columns as in the full form, Q columns sum to the column sums of the compact dQ
+    assert torch.allclose(colp_c[:, H:].double().sum(0), dqkv_c[:, H:].double().sum(0), rtol=1e-5, atol=1e-3 * (float(ref.abs().max()) + 1e-6) * 10)
+    assert torch.allclose(colp_c[:, :H].double().sum(0), dqc[:Nq].double().sum(0), rtol=1e-5, atol=1e-3 * (float(ref.abs().max()) + 1e-6) * 10)
+
+
 @pytest.mark.parametrize("ramp", [0.0, 0.02, 0.5])
 def test_attention_running_maximum(ramp):
     """The forward rescales its accumulators only when a row maximum has grown by more than 2^8 and keeps a stale
