@@ -640,5 +640,6 @@ def test_fp8_step_against_the_fp8_restatement(L, B, lens, tn8, monkeypatch):
     early = {lp + "ffn_output.weight", lp + "ffn.bias", lp + "full_layer_layer_norm.weight", "phoneme_predictor.weight"}
     for k, r_emul, r_plain, r16_emul, r16_plain in rows:
         assert r_emul < 0.06, (k, r_emul, r_plain)
-        assert r_emul < (0.75 if L > 1 else 0.35 if k in early else 0.6) * r_plain, (k, r_emul, r_plain)
+        # (four applications: 0.52-0.72 measured on the shipped build, the word embeddings — the end of the chain — closest to the bound)
+        assert r_emul < (0.8 if L > 1 else 0.35 if k in early else 0.6) * r_plain, (k, r_emul, r_plain)
         assert r16_emul < 0.8 * r16_plain and r16_plain < 0.02, (k, r16_emul, r16_plain)
