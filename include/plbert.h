@@ -219,7 +219,8 @@ int plb_poll_status(const PlbEngine* e, int32_t* ln_exchange_timeouts);
 /* For a host that runs the gradient exchange itself (torch.distributed, a foreign communicator): plb_status_export writes
  * this rank's count as one float to `out` (device) behind the loss call in `stream`; the host sums it over the ranks;
  * plb_status_import merges the sum into the word, mirrors it to the host and turns the last loss call's loss into NaN —
- * before plb_adamw_step. (With the engine's own communicator both happen inside plb_loss_fwd_bwd.) */
+ * before plb_adamw_step (the loss buffer handed to that loss call must still be valid: the import writes the NaN there).
+ * (With the engine's own communicator both happen inside plb_loss_fwd_bwd.) */
 int plb_status_export(PlbEngine* e, float* out, void* stream);
 int plb_status_import(PlbEngine* e, const float* summed, void* stream);
 /* A phoneme-only loss call evaluates the part of its LAST shared-layer application that lies behind the attention

@@ -976,10 +976,11 @@ __global__ __launch_bounds__(64) void fp8_scales_kernel(float* amax, float* scal
         const float ratio = a * used / fmt;
         if (ratio > 1.0625f) { st[4] += 1.f; st[5] = fmaxf(st[5], ratio); }   // beyond the top value by more than its rounding step
         float h[4] = {st[0], st[1], st[2], st[3]};
-        const int slot = (int)st[6] & 3;
+        unsigned int* const calls = reinterpret_cast<unsigned int*>(st + 6);   // an integer count (a float would stop at 2^24 calls)
+        const int slot = (int)(*calls & 3u);
         h[slot] = a;
         st[slot] = a;
-        st[6] += 1.f;
+        *calls += 1u;
         if ((int)blockIdx.x >= hist_from) target = fmaxf(fmaxf(h[0], h[1]), fmaxf(h[2], h[3]));
       }
       target = __shfl(target, 0);
