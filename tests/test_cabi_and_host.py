@@ -142,6 +142,47 @@ def test_validate_token_ids_and_five_tuple_staging_checks():
         validate_token_ids(bad, (2, 4), [2, 4], 10)
 
 
+def test_train_loop_reruns_a_step_the_engine_declared_invalid():
+    """run._checked (the read-back of run.train_loop / run.validate): a step the engine declared invalid — HandoffTimeout from
+    the status check right behind the loss read-back, where it is exact — is run again, at most MAX_HANDOFF_RETRIES times,
+    and the retries are logged; anything else propagates. Host logic only: a stub stands in for the trainer."""
+    from plbert_amd import run
+    from plbert_amd.engine import HandoffTimeout
+
+    class Loss:
+        def __init__(self, v): self.v = v
+        def item(self): return self.v
+
+    class Engine:
+        def __init__(self, fail): self.fail, self.checks = fail, 0
+        def raise_if_failed(self):
+            self.checks += 1
+            if self.fail > 0:
+                self.fail -= 1
+                raise HandoffTimeout("injected")
+
+    class Trainer:
+        def __init__(self, fail): self.engine, self.calls = Engine(fail), 0
+        def step(self):
+            self.calls += 1
+            return Loss(float("nan") if self.engine.fail > 0 else 1.25)
+
+    notes = []
+    tr = Trainer(fail=2)
+    assert run._checked(tr, tr.step, lambda **kw: notes.append(kw)) == 1.25
+    assert tr.calls == 3 and [n["retry"] for n in notes] == [1, 2] and all("injected" in n["handoff_timeout"] for n in notes)
+    tr = Trainer(fail=run.MAX_HANDOFF_RETRIES + 1)
+    with pytest.raises(HandoffTimeout):
+        run._checked(tr, tr.step)
+    assert tr.calls == run.MAX_HANDOFF_RETRIES + 1
+    tr = Trainer(fail=0)
+
+    def boom():
+        raise ValueError("not a hand-off matter")
+    with pytest.raises(ValueError):
+        run._checked(tr, boom)
+
+
 def test_bench_maps_profiler_classes_to_rocprof_kernel_names():
     """bench.py attributes PMC traffic to the dominant profiler class by kernel name (template arguments
     <tile, ACT, OUTF32, loop form, FP8, ABF8> of the pipeline GEMM, <ACT, OUTF32> of the 128x128 one, which is a class
