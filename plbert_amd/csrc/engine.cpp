@@ -844,7 +844,9 @@ static bool f8_call(const PlbEngine* e, int64_t Tp, bool train) {
 // zeros from their sums). Compact GEMMs of ~2,300 rows do not fill one-tile-per-CU grids, so this part runs on the
 // small-shape launches (GEMM + LayerNorm kernels, gelu by act 1 / 2): 168 -> 75 us forward, 164 -> 86 us backward, and the
 // three weight-gradient GEMMs that stack its rows read (L-1) Tp + Mc rows instead of L Tp (measured: profiles/r05_*).
-// Not taken by dual-head calls (the token loss reads every position), fp8 calls and PLBERT_PRUNE_LAST=0.
+// fp8 calls run this part in bf16 too and add the 1-byte images of the compact rows that their stacked weight-gradient
+// GEMMs read. Not taken by dual-head calls (the token loss reads every position), when more than half of the positions
+// are masked, and under PLBERT_PRUNE_LAST=0.
 struct Prune { const int32_t* rows; int n; int Mc; };
 static int g_prune_last = -1;   // test / tuning hook (plb_set_prune_last): -1 the environment's choice, 0 off, 1 on
 extern "C" void plb_set_prune_last(int on) { g_prune_last = on < 0 ? -1 : (on ? 1 : 0); }
