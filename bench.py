@@ -339,6 +339,33 @@ def pipeline_child(args):
         t = timed(lambda: fed(steps))
         res[on_copy] = (t / steps, tokens[0] / t)
         it.close()
+    t_sync = t_def = None
+    if N == 4:   # the same with the loss read back every step, as run.train_loop (and the reference, train.py:395) does
+        feeder = DeviceFeeder(loader, device=trainer.engine.device, vocab_size=cfg.vocab_size, word_separator=87)
+        it = iter(feeder)
+
+        def fed_sync(k):
+            for _ in range(k):
+                float(trainer.step(next(it)).item())
+        fed_sync(warm)
+        t_sync = timed(lambda: fed_sync(steps)) / steps
+
+        from plbert_amd.run import _LossReader   # ... and read back one step late (run.train_loop's default): no stall
+        rd = _LossReader(trainer.engine.device)
+
+        def fed_deferred(k):
+            h = None
+            for _ in range(k):
+                h2 = rd.post(trainer.step(next(it)))
+                if h is not None:
+                    rd.read(h)
+                h = h2
+            rd.read(h)
+        it.close()
+        it = iter(feeder)                        # (a new epoch of the loader: an epoch holds warm-up + timed steps once)
+        fed_deferred(warm)
+        t_def = timed(lambda: fed_deferred(steps)) / steps
+        it.close()
     assert trainer.engine.status()["ln_exchange_timeouts"] == 0
     t_pipe, rate = res[True]
     out = {"workers": N, "dtype": args.dtype, "ms_per_step": round(t_pipe * 1e3, 3), "tokens_per_s": round(rate, 1),
@@ -348,6 +375,9 @@ def pipeline_child(args):
            "steps": steps, "host_cores": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count()}
     if False in res:
         out["mask_on_compute_stream_ms_per_step"] = round(res[False][0] * 1e3, 3)
+    if t_sync is not None:
+        out["with_loss_readback_every_step_ms_per_step"] = round(t_sync * 1e3, 3)
+        out["with_deferred_loss_readback_ms_per_step"] = round(t_def * 1e3, 3)
     os.dup2(real_stdout, 1)
     print(json.dumps(out), flush=True)
     os._exit(0)   # worker processes of a persistent DataLoader: do not wait for their teardown

@@ -183,6 +183,72 @@ def test_train_loop_reruns_a_step_the_engine_declared_invalid():
         run._checked(tr, boom)
 
 
+@pytest.mark.parametrize("deferred", [True, False])
+@pytest.mark.parametrize("fail_at", [(), (0,), (2,), (3,), (5,), (1, 4)])
+def test_train_loop_with_deferred_readback_applies_every_batch_once_in_order(monkeypatch, deferred, fail_at):
+    """run.train_loop reads the loss of step i back after step i + 1 has been enqueued (no stall). Host logic against a
+    simulated device: a step the engine declares invalid is left out on the 'device' together with everything enqueued
+    behind it until the host has read the status (the sticky word), and the loop must end with EVERY batch applied exactly
+    once, in order, the records 1..N in order, checkpoints / validation exactly at the interval boundaries and never a step
+    enqueued beyond num_steps — whichever step fails (first, last of an interval, last of the run, two of them)."""
+    from plbert_amd import run
+    from plbert_amd.engine import HandoffTimeout
+
+    class Device:
+        def __init__(self):
+            self.applied, self.sticky, self.skipped, self.enqueued = [], False, 0, 0
+
+    dev = Device()
+
+    class Engine:
+        device = "sim"
+
+        def raise_if_failed(self):
+            if dev.sticky:
+                n, dev.sticky, dev.skipped = dev.skipped, False, 0
+                err = HandoffTimeout(f"{n} skipped")
+                err.skipped_updates = n
+                raise err
+
+    class Trainer:
+        engine = Engine()
+
+        def step(self, batch):
+            self.engine.raise_if_failed()                   # what HipEngine._loss_call does first
+            n, dev.enqueued = dev.enqueued, dev.enqueued + 1
+            if n in fail_at or dev.sticky:
+                dev.sticky, dev.skipped = True, dev.skipped + 1
+                return _Loss(float("nan"))
+            dev.applied.append(batch)
+            return _Loss(float(batch))
+
+    class _Loss(float):
+        def item(self): return float(self)
+
+    class Reader:
+        def post(self, loss): return loss
+        def read(self, h): return float(h)
+
+    N, interval = 6, 3
+    events = []
+    monkeypatch.setattr(run, "_batches", lambda *a, **k: iter(range(100)))
+    monkeypatch.setattr(run, "validate", lambda *a, **k: (events.append(("validate", len(dev.applied), dev.enqueued)), 0.5)[1])
+    monkeypatch.setattr(run, "save_checkpoint", lambda tr, step, *a: events.append(("save", step, list(dev.applied))))
+    monkeypatch.setattr(run, "world_info", lambda *a: (0, 2))          # (no DeviceFeeder budget in this test)
+    recs = []
+    step, epoch = run.train_loop(Trainer(), None, None, 0, N, interval, 2, lambda **kw: recs.append(kw), "unused",
+                                 deferred_readback=deferred, reader=Reader())
+    assert step == N and dev.applied == list(range(N))                 # every batch once, in order, none beyond num_steps
+    assert dev.enqueued >= N + len(fail_at)                             # (each invalid step and what was enqueued behind it ran again)
+    losses = [r for r in recs if "phoneme_loss" in r]
+    assert [r["step"] for r in losses] == list(range(1, N + 1)) and [r["phoneme_loss"] for r in losses] == [float(i) for i in range(N)]
+    saves = [e for e in events if e[0] == "save"]
+    assert [(e[1], e[2]) for e in saves] == [(3, [0, 1, 2]), (6, [0, 1, 2, 3, 4, 5])]      # checkpoints on the reference's weights
+    vals = [e for e in events if e[0] == "validate"]
+    assert [e[1] for e in vals] == [0, 3, 6] and all(e[1] == len([b for b in range(e[1])]) for e in vals)
+    assert len([r for r in recs if "handoff_timeout" in r]) >= len(fail_at) > 0 or not fail_at
+
+
 def test_bench_maps_profiler_classes_to_rocprof_kernel_names():
     """bench.py attributes PMC traffic to the dominant profiler class by kernel name (template arguments
     <tile, ACT, OUTF32, loop form, FP8, ABF8> of the pipeline GEMM, <ACT, OUTF32> of the 128x128 one, which is a class
