@@ -175,23 +175,49 @@ def _feeder(loader, trainer, word_separator, budget=None):
     return f
 
 
-def _batches(loader, trainer, device_masking, word_separator, budget=None):
-    """Collated batches of the loader as device-resident StagedBatch objects: this rank's contiguous slice of every
-    global batch (accelerate's split_batches=True), copies overlapped with compute (DeviceFeeder) on one GPU.
-    ``budget``: see DeviceFeeder.draw_budget (the training loader: draws are granted up to the next validation)."""
+class _ShardedLoader:
+    """This rank's contiguous slice of every collated batch of ``loader`` (accelerate's split_batches=True, train.py:220 —
+    ``dist.shard_batch``; a short last validation batch is completed as accelerate's even_batches=True does). An iterable
+    like the loader itself, so the same DeviceFeeder (pinned buffer, copy stream, double-buffered device slots) feeds a
+    data-parallel rank: every rank still draws the masks of the WHOLE global batch from its own copy of the reference's
+    streams, as the reference's ranks do."""
+
+    def __init__(self, loader, rank, world):
+        self.loader, self.rank, self.world = loader, rank, world
+        self.batch_size = getattr(loader, "batch_size", None)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        first = None
+        for batch in self.loader:
+            cur = (np.asarray(batch[0]), np.asarray(batch[1]), batch[2], batch[3])
+            if first is None:
+                first = cur
+            yield shard_batch(cur, self.rank, self.world, pad=True, batch_size=self.batch_size, first_batch=first)
+
+
+def _source(loader, trainer):
+    """What this rank's feeder iterates: the loader itself on one GPU, its sharded view under a launcher (one view per
+    loader, kept with the trainer so that the feeder cache — keyed by the object it iterates — finds it again)."""
+    import weakref
     rank, world = world_info()
     if world == 1:
-        yield from _feeder(loader, trainer, word_separator, budget)
-        return
-    first = None
-    for batch in loader:
-        cur = (np.asarray(batch[0]), np.asarray(batch[1]), batch[2], batch[3])
-        if first is None:
-            first = cur
-        # a short last (validation) batch: accelerate's even_batches=True completes it from the pass's first batch
-        lab, msk, lens, idx = shard_batch(cur, rank, world, pad=True, batch_size=getattr(loader, "batch_size", None),
-                                          first_batch=first)
-        yield trainer.stage_batch(lab, msk, lens, idx)
+        return loader
+    views = trainer.__dict__.setdefault("_sharded_views", weakref.WeakKeyDictionary())
+    v = views.get(loader)
+    if v is None:
+        v = views[loader] = _ShardedLoader(loader, rank, world)
+    return v
+
+
+def _batches(loader, trainer, device_masking, word_separator, budget=None):
+    """Collated batches of the loader as device-resident StagedBatch objects: this rank's contiguous slice of every
+    global batch (accelerate's split_batches=True), copies overlapped with compute (DeviceFeeder) — on one GPU and, since
+    round 5, on every rank of a data-parallel run (it staged each batch with blocking copies before).
+    ``budget``: see DeviceFeeder.draw_budget (the training loader: draws are granted up to the next validation)."""
+    yield from _feeder(_source(loader, trainer), trainer, word_separator, budget)
 
 
 MAX_HANDOFF_RETRIES = 3
@@ -266,16 +292,15 @@ def train_loop(trainer, train_loader, val_loader, current_step, num_steps, save_
     window = deque(maxlen=log_interval)
     epoch = 0
     log(val_phoneme_loss=validate(trainer, val_loader, device_masking, word_separator), step=current_step, epoch=epoch)
-    single = world_info()[1] == 1
+    train_feeder = _feeder(_source(train_loader, trainer), trainer, word_separator, 0)
 
     def grant():
         # the training producer may draw up to the next validation point and no further: the validation pass then sees the
-        # global masking streams exactly where the reference's single-threaded loop leaves them (train.py:369-373)
-        if single:
-            _feeder(train_loader, trainer, word_separator, 0).grant(save_interval - current_step % save_interval)
+        # global masking streams exactly where the reference's single-threaded loop leaves them (train.py:369-373) — on
+        # every rank of a data-parallel run alike (each rank draws the global batch's masks, as the reference's ranks do)
+        train_feeder.grant(save_interval - current_step % save_interval)
 
-    if single:  # permits an earlier loop with this trainer and loader left unused (it stopped at num_steps mid-interval)
-        _feeder(train_loader, trainer, word_separator, 0).reset_budget(0)
+    train_feeder.reset_budget(0)   # permits an earlier loop with this trainer and loader left unused (it stopped mid-interval)
     grant()
     if reader is None:
         reader = _LossReader(trainer.engine.device)

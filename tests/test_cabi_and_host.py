@@ -234,7 +234,14 @@ def test_train_loop_with_deferred_readback_applies_every_batch_once_in_order(mon
     monkeypatch.setattr(run, "_batches", lambda *a, **k: iter(range(100)))
     monkeypatch.setattr(run, "validate", lambda *a, **k: (events.append(("validate", len(dev.applied), dev.enqueued)), 0.5)[1])
     monkeypatch.setattr(run, "save_checkpoint", lambda tr, step, *a: events.append(("save", step, list(dev.applied))))
-    monkeypatch.setattr(run, "world_info", lambda *a: (0, 2))          # (no DeviceFeeder budget in this test)
+    grants = []
+
+    class Budget:                                                        # stands in for the training loader's DeviceFeeder
+        def grant(self, n): grants.append(n)
+        def reset_budget(self, n=0): grants.append(("reset", n))
+
+    monkeypatch.setattr(run, "_source", lambda loader, trainer: loader)
+    monkeypatch.setattr(run, "_feeder", lambda *a, **k: Budget())
     recs = []
     step, epoch = run.train_loop(Trainer(), None, None, 0, N, interval, 2, lambda **kw: recs.append(kw), "unused",
                                  deferred_readback=deferred, reader=Reader())
@@ -247,6 +254,7 @@ def test_train_loop_with_deferred_readback_applies_every_batch_once_in_order(mon
     vals = [e for e in events if e[0] == "validate"]
     assert [e[1] for e in vals] == [0, 3, 6] and all(e[1] == len([b for b in range(e[1])]) for e in vals)
     assert len([r for r in recs if "handoff_timeout" in r]) >= len(fail_at) > 0 or not fail_at
+    assert grants == [("reset", 0), 3, 3, 3]                             # draws granted interval by interval (start, step 3, step 6)
 
 
 def test_bench_maps_profiler_classes_to_rocprof_kernel_names():
