@@ -228,8 +228,13 @@ class DecisionsDataset(torch.utils.data.Dataset):
         return self.dataset.decisions(idx)
 
 
-def build_dataloader(df, batch_size, device, dataset_config, use_token_ids, num_workers=0, decisions=False, **kwargs):
+def build_dataloader(df, batch_size, device, dataset_config, use_token_ids, num_workers=0, decisions=False, shard=None,
+                     **kwargs):
     """95/5 train/val split by ``random.shuffle`` then two DataLoaders (dataloader.py:225-274).
+    ``shard=(rank, world)`` (not in the reference, whose every rank loads — and masks — the WHOLE global batch and keeps a
+    slice, accelerate split_batches=True): this rank's loaders hold every world-th sample of the split and batches of
+    ``batch_size // world``, so the host work per rank is 1 / world of the reference's; the global batch is still
+    ``batch_size`` distinct samples per step, but which samples meet in it differs from the reference's order.
     ``num_workers > 0`` (the reference runs 0, train.py:253 — the single-threaded Python masking is its input
     bottleneck): worker processes with independent, reproducible masking streams (``seed_worker``).
     ``decisions=True``: batches are ``collate_decisions`` dicts for ``plbert_amd.pipeline.DeviceFeeder`` /
@@ -241,13 +246,19 @@ def build_dataloader(df, batch_size, device, dataset_config, use_token_ids, num_
     val_size = min(int(total * 0.05), 10000)
     order = list(range(total))
     random.shuffle(order)
-    train_set = Subset(dataset, order[: total - val_size])
-    val_set = Subset(dataset, order[total - val_size:])
+    train_idx, val_idx = order[: total - val_size], order[total - val_size:]
+    if shard is not None:
+        rank, world = shard
+        if batch_size % world:
+            raise ValueError(f"batch_size {batch_size} is not divisible by the world size {world}")
+        train_idx, val_idx, batch_size = train_idx[rank::world], val_idx[rank::world], batch_size // world
+    train_set = Subset(dataset, train_idx)
+    val_set = Subset(dataset, val_idx)
     collate = Collater() if use_token_ids else PhonemeOnlyCollater()
     pin = device != "cpu"
     if decisions:
-        train_set = Subset(DecisionsDataset(dataset), order[: total - val_size])
-        val_set = Subset(DecisionsDataset(dataset), order[total - val_size:])
+        train_set = Subset(DecisionsDataset(dataset), train_idx)
+        val_set = Subset(DecisionsDataset(dataset), val_idx)
         collate, pin = collate_decisions, False
     if num_workers > 0:
         kwargs.setdefault("worker_init_fn", seed_worker)
@@ -256,6 +267,8 @@ def build_dataloader(df, batch_size, device, dataset_config, use_token_ids, num_
                               collate_fn=collate, pin_memory=pin, num_workers=num_workers, **kwargs)
     val_loader = DataLoader(val_set, batch_size=batch_size, shuffle=False, drop_last=False,
                             collate_fn=collate, pin_memory=pin, num_workers=num_workers, **kwargs)
+    if shard is not None:
+        train_loader.plb_per_rank = val_loader.plb_per_rank = True   # (run._source: nothing left to slice)
     return train_loader, val_loader
 
 

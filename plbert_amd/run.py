@@ -203,7 +203,7 @@ def _source(loader, trainer):
     loader, kept with the trainer so that the feeder cache — keyed by the object it iterates — finds it again)."""
     import weakref
     rank, world = world_info()
-    if world == 1:
+    if world == 1 or getattr(loader, "plb_per_rank", False):   # (build_dataloader(shard=...): already this rank's samples)
         return loader
     views = trainer.__dict__.setdefault("_sharded_views", weakref.WeakKeyDictionary())
     v = views.get(loader)
@@ -380,15 +380,19 @@ def train(args=None, dataset=None, device=None):
         dataset = load_dataset(tp["training_dataset"], split=tp["split"])
     device_masking = bool(tp.get("device_masking", False))
     _, world = world_info()
+    # training_params.shard_samples (not in the reference's config.yml): each rank loads and masks only its own samples
+    # instead of the whole global batch (build_dataloader(shard=...)); the device-side masking then works under a launcher too
+    shard = (world_info()[0], world) if world > 1 and bool(tp.get("shard_samples", False)) else None
+    decisions = device_masking and (world == 1 or shard is not None)
     train_loader, val_loader = build_dataloader(dataset, batch_size=int(tp["batch_size"]), device="cuda", dataset_config=dp,
                                                 use_token_ids=False, num_workers=int(tp.get("num_workers", 0)),
-                                                decisions=device_masking and world == 1)
+                                                decisions=decisions, shard=shard)
     trainer, current_step = initialize_model(config, log_dir, resuming, device=device)
     log = _Log(log_dir, main)
     print("Start training...")
     current_step, epoch = train_loop(trainer, train_loader, val_loader, current_step, int(tp["num_steps"]),
                                      int(tp["save_interval"]), int(tp["log_interval"]), log, log_dir,
-                                     device_masking and world == 1, dp.get("word_separator"))
+                                     decisions, dp.get("word_separator"))
     print(f"Training completed at step {current_step}, epoch {epoch}")
     if dist.is_available() and dist.is_initialized():
         dist.barrier()

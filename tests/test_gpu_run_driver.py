@@ -95,14 +95,17 @@ def _launched_rank(rank, world, port, args, docs, out):
     dist.destroy_process_group()
 
 
-def test_train_under_a_launcher_two_ranks(tmp_path):
+@pytest.mark.parametrize("sharded", [False, True])
+def test_train_under_a_launcher_two_ranks(tmp_path, sharded):
     """``train(args)`` started as two ranks (RANK / WORLD_SIZE / LOCAL_RANK in the environment, nothing else): each rank
     joins the process group itself and takes GPU LOCAL_RANK (both map to the box's one GPU here), rank 0 alone creates
     the run directory, writes metrics and checkpoints, the ragged last validation batch (7 documents, batch 4, two
-    ranks) is shared out instead of raising, and the replicas end bit-identical."""
+    ranks) is shared out instead of raising, and the replicas end bit-identical. Every rank's batches come through the
+    DeviceFeeder (copy stream, double-buffered slots). ``sharded``: training_params.shard_samples — each rank loads and masks
+    only its own half of the samples (batches of 2), with the masking applied on the device."""
     import torch.multiprocessing as mp
 
-    path = _config(tmp_path, 4)
+    path = _config(tmp_path, 4, **(dict(shard_samples=True, device_masking=True, num_workers=2) if sharded else {}))
     args = {"config_path": path, "run_name": "two"}
     docs = (_docs() * 3)[:140]                            # 5 % validation split = 7 documents: batches of 4 and 3
     assert len(docs) == 140
