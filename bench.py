@@ -856,6 +856,9 @@ def main():
 
     if rank == 0:
         tokens = world * B * S * args.steps
+        rows_done, rows_of = eng.last_application_rows()
+        executed = round(1.0 - 3.0 * (2 * cfg.hidden_size ** 2 + 4 * cfg.hidden_size * cfg.intermediate_size) *
+                         max(0, rows_of - rows_done) / (flop_per_token * B * S), 4)
         out = {
             "metric": "phoneme-tokens/sec", "value": round(tokens / dt, 1), "unit": "tokens/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -870,9 +873,9 @@ def main():
             # (rows, of): the post-attention part of the LAST application runs on the masked rows only in a phoneme-only
             # call (include/plbert.h: plb_last_application_rows) — same loss and gradients, ~5 % of the credited FLOPs not executed
             "last_application_rows": list(eng.last_application_rows()),
-            "credited_flops_executed": round(1.0 - 3.0 * (2 * cfg.hidden_size ** 2 + 4 * cfg.hidden_size * cfg.intermediate_size) *
-                                             max(0, eng.last_application_rows()[1] - eng.last_application_rows()[0]) /
-                                             (flop_per_token * B * S), 4),
+            "credited_flops_executed": executed,
+            # the same fraction counting only the FLOPs that were executed (what the MFMA pipes actually did)
+            "step_mfma_frac_executed": round(executed * flop_per_token * B * S / (dt / args.steps) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4),
             "ranks_seen": ranks_seen, "comm": comm_info, "staged": staged,
             # in-launch hand-offs of the LayerNorm-in-GEMM kernels that timed out over the whole run: must be 0
             "ln_exchange_timeouts": eng.status()["ln_exchange_timeouts"],
