@@ -168,12 +168,12 @@ int plb_adamw_step(PlbEngine* e, double lr, double beta1, double beta2, double e
 int plb_set_fp8(PlbEngine* e, int32_t on, void* stream);
 int plb_fp8_state(const PlbEngine* e, int32_t* enabled, int32_t* calibrated);
 /* Delayed scaling and its limits. Every operand site quantises a call's values with the scale the PREVIOUS calls' maxima
- * gave: activations (e4m3) map the last call's maximum to 448; gradients (e5m2) map the LARGEST maximum of the last four
- * calls to 28672 = half the format's range. A call whose gradients exceed 2x everything seen in the last four calls
- * (activations: 1x the last call) has the excess CLAMPED in every dX and weight-gradient operand of that site — silently
- * as far as the loss goes. plb_fp8_stats makes it visible: per site (order: x, a, gelu(u), context; dpre2, dU, dpre1,
- * dQKV), the number of calls since plb_set_fp8 in which values were clamped by more than the top value's rounding step
- * (true maximum x scale > 1.0625 x format maximum) and the worst such overshoot. Synchronises `stream`. No reference counterpart (the reference has no fp8 path). */
+ * gave — the LARGEST maximum of the last four calls: activations (e4m3) map it to 448, gradients (e5m2) to 28672 = half the
+ * format's range. A call whose values exceed everything seen in the last four calls (gradients: 2x that) has the excess
+ * CLAMPED in every GEMM operand of that site — silently as far as the loss goes. plb_fp8_stats makes it visible: per site
+ * (order: x, a, gelu(u), context; dpre2, dU, dpre1, dQKV), the number of calls since plb_set_fp8 in which values were
+ * clamped by more than the top value's rounding step (true maximum x scale > 1.0625 x format maximum) and the worst such
+ * overshoot. Synchronises `stream`. No reference counterpart (the reference has no fp8 path). */
 int plb_fp8_stats(PlbEngine* e, float clamped_calls[8], float worst_overshoot[8], void* stream);
 
 /* The token head (trained by dual-head steps only) keeps its own AdamW step count, as torch keeps one per parameter

@@ -952,9 +952,9 @@ __global__ __launch_bounds__(256) void amax_kernel(const void* X, size_t rows, i
 // stats (or null): 8 floats per group — [0..3] the last four non-zero maxima of the group, [4] how many calls quantised
 // values beyond the format's range by more than the top value's rounding step (this call's true maximum x the scale it was
 // quantised with > 1.0625 fmt: those elements were clamped and it shows), [5] the worst such ratio, [6] maxima recorded so far (selects the history slot). Groups from hist_from on
-// (the gradient sites) take their scale from the LARGEST maximum of the history instead of the last one: a step whose
-// gradients are several times the previous step's (a short final batch, the step after a validation pass, a loss
-// spike) is then clamped only if it exceeds everything seen in four calls, and the clamp is counted either way.
+// (the engine: every site) take their scale from the LARGEST maximum of the history instead of the last one: a step whose
+// values are larger than the previous step's (a short final batch, the step after a validation pass, a loss spike, or just
+// another batch) is then clamped only if it exceeds everything seen in four calls, and the clamp is counted either way.
 __global__ __launch_bounds__(64) void fp8_scales_kernel(float* amax, float* scale, float* deq, int n, float fmax, int group,
                                                         int n2, float fmax2, float* stats, int hist_from, float fmt, float fmt2) {
   const int g0 = blockIdx.x * group, lane = threadIdx.x;
