@@ -80,6 +80,30 @@ def test_run_directory_checkpoints_and_resume(tmp_path, device_masking):
     assert not resuming and not [f for f in os.listdir(run_dir) if f.startswith("step_")]
 
 
+@pytest.mark.parametrize("num_workers", [0, 2])
+def test_deferred_loss_readback_logs_what_the_immediate_one_logs(tmp_path, monkeypatch, num_workers):
+    """train_loop reads every step's loss one step late (run._LossReader: no stall between steps); the records — losses,
+    running means, validation losses, their order — and the final weights must be those of the loop that reads each loss
+    before enqueuing the next step, as the reference does (train.py:381-410)."""
+    out = {}
+    loop = prun.train_loop
+    for deferred in (True, False):
+        sub = tmp_path / ("deferred" if deferred else "immediate")
+        sub.mkdir()
+        path = _config(sub, 7, device_masking=True, num_workers=num_workers)
+        monkeypatch.setattr(prun, "train_loop", lambda *a, _d=deferred, **kw: loop(*a, deferred_readback=_d, **kw))
+        torch.manual_seed(0)
+        pdata.seed_reference_streams(1)
+        trainer, step, _ = prun.train({"config_path": path, "run_name": "r"}, dataset=_docs())
+        assert step == 7
+        recs = [json.loads(l) for l in (sub / "runs" / "r" / "metrics.jsonl").read_text().splitlines()]
+        out[deferred] = (recs, trainer.engine.params.clone())
+        del trainer
+    assert out[True][0] == out[False][0]
+    assert torch.equal(out[True][1], out[False][1])
+    assert [r["step"] for r in out[True][0] if "phoneme_loss" in r] == list(range(1, 8))
+
+
 def _launched_rank(rank, world, port, args, docs, out):
     # what torchrun / accelerate launch export: train() must join the group and pick its GPU from these alone
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
