@@ -703,11 +703,12 @@ def main():
             tr = eng.comm_trace_read()
             eng.comm_trace(False)
             names = {0: "embeddings+map-in+LN2", eng.layout["phoneme_predictor.weight"][0]: "phoneme head"}
-            for k in ("query.weight", "query.bias", "ffn.weight", "ffn.bias", "ffn_output.weight", "ffn_output.bias"):
-                full = "encoder.encoder.albert_layer_groups.0.albert_layers.0." + ("attention." if k.startswith("query") else "") + k
-                names[eng.layout[full][0]] = {"query.weight": "Q/K/V weights", "query.bias": "QKV biases+dense+LN1", "ffn.weight": "ffn.weight",
-                                              "ffn.bias": "ffn.bias", "ffn_output.weight": "ffn_output.weight",
-                                              "ffn_output.bias": "ffn_output.bias"}[k]
+            lay = "encoder.encoder.albert_layer_groups.0.albert_layers.0."
+            for k, what in (("attention.query.weight", "Q/K/V weights"), ("attention.query.bias", "Q/K/V biases"),
+                            ("attention.dense.weight", "dense.weight"), ("attention.dense.bias", "dense.bias+LN1"),
+                            ("ffn.weight", "ffn.weight"), ("ffn.bias", "ffn.bias"), ("ffn_output.weight", "ffn_output.weight"),
+                            ("ffn_output.bias", "ffn_output.bias")):
+                names[eng.layout[lay + k][0]] = what
             for pc in tr["pieces"]:
                 pc["what"] = names.get(pc["range"][0], "token head" if pc["range"][0] > eng.trainable else "?")
                 pc["MB"] = round((pc["range"][1] - pc["range"][0]) * 4 / 1e6, 2)

@@ -231,7 +231,7 @@ int plb_status_import(PlbEngine* e, const float* summed, void* stream);
  * (padded to 128), of = the call's padded token count (rows == of: every row — a dual-head call, an fp8 call, more than
  * half of the positions masked, or PLBERT_PRUNE_LAST=0). */
 int plb_last_application_rows(const PlbEngine* e, int64_t* rows, int64_t* of);
-/* What the last training step exchanged: the number of collectives it issued (8 pieces for the reference's phoneme-only
+/* What the last training step exchanged: the number of collectives it issued (10 pieces for the reference's phoneme-only
  * step with overlap on, 1 with overlap off; one more after a dual-head step) and the floats they covered. The reference
  * has no counterpart (DDP's bucket count is internal to torch, train.py:218-221); a caller logs it to see which form of
  * the exchange actually ran. */

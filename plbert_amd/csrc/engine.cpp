@@ -1296,10 +1296,11 @@ static int loss_impl(PlbEngine* e, bool backward, const int64_t* masked_ids, con
         // sequence must be the same on every rank, so this rank issues the very same ranges in the very same order
         // (its zeros), not one all-reduce of the whole buffer.
         const int64_t* o = e->poff;
-        const int64_t ranges[8][2] = {{o[PLB_HEAD_W], e->ptrain}, {o[PLB_Q_W], o[PLB_Q_B]}, {o[PLB_FFN_W], o[PLB_FFN_B]},
-                                      {o[PLB_FFNO_W], o[PLB_FFNO_B]}, {0, o[PLB_Q_W]}, {o[PLB_Q_B], o[PLB_FFN_W]},
-                                      {o[PLB_FFN_B], o[PLB_FFNO_W]}, {o[PLB_FFNO_B], o[PLB_HEAD_W]}};
-        for (int i = 0; i < 8; ++i) {
+        const int64_t ranges[10][2] = {{o[PLB_HEAD_W], e->ptrain}, {o[PLB_Q_W], o[PLB_Q_B]}, {o[PLB_FFN_W], o[PLB_FFN_B]},
+                                       {0, o[PLB_Q_W]}, {o[PLB_Q_B], o[PLB_DENSE_W]}, {o[PLB_DENSE_B], o[PLB_FFN_W]},
+                                       {o[PLB_FFN_B], o[PLB_FFNO_W]}, {o[PLB_FFNO_B], o[PLB_HEAD_W]}, {o[PLB_FFNO_W], o[PLB_FFNO_B]},
+                                       {o[PLB_DENSE_W], o[PLB_DENSE_B]}};
+        for (int i = 0; i < 10; ++i) {
           HB_W(s, e->grads + ranges[i][0], (ranges[i][1] - ranges[i][0]) * 4, "zero gradients of a rank without masked phonemes");
           if (reduce_piece(e, ranges[i][0], ranges[i][1], s)) return 1;
           if (i == 0 && status_exchange(e, s)) return 1;   // where a regular step issues it: behind the head piece
@@ -1738,9 +1739,9 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   TRY(plb_launch_copy_cols(scratch2, 64, 3 * H, 2 * H, H, e->grd(PLB_FFNO_B), s2));
   if (s2 != s) HIPTRY(ev_record(e, e->ev_join, s2));
   // main stream: shared-layer weight gradients, one token-major GEMM per weight over all L applications ------------
-  // Overlapped exchange: a weight's range travels as soon as its GEMM (+ slab reduction) has written it. The small
-  // tensors between the weights in the flat order (biases, LayerNorm, embeddings) come from the side stream, which needs
-  // about as long as the first three GEMMs: they go last, behind the join, so the main stream never waits for it early.
+  // Overlapped exchange: a weight's range travels as soon as its GEMM (+ slab reduction) has written it; the small
+  // tensors between the weights in the flat order (biases, LayerNorm, embeddings) travel behind the SIDE stream's event
+  // (below, after the first weight's piece); the smallest weight goes last.
   const bool ov = overlapping(e);
   const bool t8 = e->tn8_call;   // fp8 call: gradient (e5m2) x activation (e4m3) images of all L applications
   float* const slab = e->at<float>(e->o_slab);
@@ -1752,6 +1753,21 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_du8), e->at<uint8_t>(e->o_a8), Mtot_c, I, H, F8_DU, F8_A, e->grd(PLB_FFN_W), s)
          : weight_grad(e, e->at<bf16_t>(e->o_du), I, I, e->at<bf16_t>(e->o_a), H, Mtot_c, I, H, e->grd(PLB_FFN_W), s)) return 1;
   if (ov && reduce_piece(e, e->poff[PLB_FFN_W], e->poff[PLB_FFN_B], s)) return 1;
+  if (ov) {
+    // The small tensors between the weights in the flat order (embeddings + map-in + LayerNorm 2 | Q/K/V biases | dense.bias +
+    // LayerNorm 1 | ffn.bias | ffn_output.bias) all come from the side stream, which is done after about three of the four
+    // GEMMs: their pieces are released by the SIDE stream's own event (everything it does in this call has been enqueued
+    // above), behind the second weight's piece in the communication stream's queue (the side stream, stretched by the
+    // GEMMs it runs beside, ends between GEMM 2 and GEMM 3: piece_trace) — five latency-bound all-reduces that
+    // travel beside the remaining GEMMs instead of after the last one (they were the step's exposed tail at world > 1:
+    // four collectives in a row behind the join). The main stream joins the side stream at the end of the tail as before.
+    const int64_t* o = e->poff;
+    if (reduce_piece(e, 0, o[PLB_Q_W], s2)) return 1;
+    if (reduce_piece(e, o[PLB_Q_B], o[PLB_DENSE_W], s2)) return 1;
+    if (reduce_piece(e, o[PLB_DENSE_B], o[PLB_FFN_W], s2)) return 1;
+    if (reduce_piece(e, o[PLB_FFN_B], o[PLB_FFNO_W], s2)) return 1;
+    if (reduce_piece(e, o[PLB_FFNO_B], o[PLB_HEAD_W], s2)) return 1;
+  }
   HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_FFNO_W), (int64_t)I * H * 4, "ffn_output.weight gradient");
   if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp8), e->at<uint8_t>(e->o_g8), Mtot_c, H, I, F8_DP, F8_G, e->grd(PLB_FFNO_W), s)
          : weight_grad(e, e->at<bf16_t>(e->o_dpre2), H, H, e->at<bf16_t>(e->o_g), I, Mtot_c, H, I, e->grd(PLB_FFNO_W), s)) return 1;
@@ -1759,13 +1775,7 @@ static int backward_tail_streams(PlbEngine* e, const int64_t* masked_ids, bf16_t
   HB_W(s, slab, e->slab_floats * 4, "weight-gradient slab"); HB_W(s, e->grd(PLB_DENSE_W), (int64_t)H * H * 4, "dense.weight gradient");
   if (t8 ? weight_grad8(e, e->at<uint8_t>(e->o_dp18), e->at<uint8_t>(e->o_c8), Mtot_c, H, H, F8_DP1, F8_C, e->grd(PLB_DENSE_W), s)
          : weight_grad(e, e->at<bf16_t>(e->o_dpre1), H, H, e->at<bf16_t>(e->o_ctx), H, Mtot_c, H, H, e->grd(PLB_DENSE_W), s)) return 1;
-  if (ov) {
-    if (s2 != s) HIPTRY(ev_wait(e, s, e->ev_join));
-    if (reduce_piece(e, 0, e->poff[PLB_Q_W], s)) return 1;                    // embeddings, map-in, LN2
-    if (reduce_piece(e, e->poff[PLB_Q_B], e->poff[PLB_FFN_W], s)) return 1;  // QKV biases, dense (the smallest weight), LN1
-    if (reduce_piece(e, e->poff[PLB_FFN_B], e->poff[PLB_FFNO_W], s)) return 1;
-    if (reduce_piece(e, e->poff[PLB_FFNO_B], e->poff[PLB_HEAD_W], s)) return 1;
-  }
+  if (ov && reduce_piece(e, e->poff[PLB_DENSE_W], e->poff[PLB_DENSE_B], s)) return 1;   // the smallest weight goes last
   return 0;
 }
 

@@ -121,18 +121,18 @@ def _check(res, expect_pieces_overlap):
             losses, params, pieces = res[r][0][key]
             assert losses == res[r][0][("torch", True)][0], (key, r)         # local losses: the exchange does not touch them
             assert np.array_equal(params, ref0[1]), (key, r)                 # bit-identical to the gloo exchange, on both ranks
-            assert pieces[0] == (expect_pieces_overlap if key[1] else expect_pieces_overlap - 7), (key, pieces)
+            assert pieces[0] == (expect_pieces_overlap if key[1] else expect_pieces_overlap - 9), (key, pieces)
 
 
 def test_piecewise_exchange_world2_matches_gloo(fake_lib):
-    """Overlapped (8 pieces inside plb_loss_fwd_bwd) and serial (one all-reduce in plb_allreduce_grads) forms."""
-    _check(_run_world2(fake_lib), expect_pieces_overlap=8)
+    """Overlapped (10 pieces inside plb_loss_fwd_bwd) and serial (one all-reduce in plb_allreduce_grads) forms."""
+    _check(_run_world2(fake_lib), expect_pieces_overlap=10)
 
 
 def test_piecewise_exchange_world2_on_the_bench_model(fake_lib):
     """The same on the model and launch forms the bench runs (768 / 12, 1024 tokens per rank: LayerNorm in the GEMM epilogues,
     gelu-derivative stash, big-tile weight-gradient GEMMs with the pieces issued between them)."""
-    _check(_run_world2(fake_lib, real=True), expect_pieces_overlap=8)
+    _check(_run_world2(fake_lib, real=True), expect_pieces_overlap=10)
 
 
 def test_piecewise_exchange_world2_fp8_calls(fake_lib):
@@ -140,21 +140,21 @@ def test_piecewise_exchange_world2_fp8_calls(fake_lib):
     rank quantises under its OWN delayed scales (the maxima are local; the weights' are identical), and the scale update
     at the end of the call must not disturb the exchange — the replicas stay bit-identical to the gloo exchange of the
     same fp8 steps, in the overlapped and in the serial form."""
-    _check(_run_world2(fake_lib, real=True, fp8=True), expect_pieces_overlap=8)
+    _check(_run_world2(fake_lib, real=True, fp8=True), expect_pieces_overlap=10)
 
 
 def test_zero_masked_rank_issues_the_same_collectives(fake_lib):
     """Rank 1's shard has no masked phoneme: its loss call takes the early-return path (train.py:129) and must replay the
-    8 ranges in the order a regular step issues them — a different sequence would deadlock or, worse, sum mismatched
+    10 ranges in the order a regular step issues them — a different sequence would deadlock or, worse, sum mismatched
     ranges; the stand-in checks (kind, count) of every collective across the ranks."""
     res = _run_world2(fake_lib, empty_rank=1)
-    _check(res, expect_pieces_overlap=8)
+    _check(res, expect_pieces_overlap=10)
     assert res[1][0][("rccl", True)][0] == [0.0, 0.0, 0.0]
 
 
 def test_dual_head_token_piece_world2(fake_lib):
-    """Dual-head step: the token head's gradients travel as a ninth piece (two all-reduces in the serial form)."""
-    _check(_run_world2(fake_lib, num_tokens=512), expect_pieces_overlap=9)
+    """Dual-head step: the token head's gradients travel as an eleventh piece (two all-reduces in the serial form)."""
+    _check(_run_world2(fake_lib, num_tokens=512), expect_pieces_overlap=11)
 
 
 def test_forgotten_piece_is_caught(fake_lib):
@@ -175,7 +175,7 @@ labels, masked, lens, idx = plbert_amd.synthetic_batch(2, 64, seed=3)
 tr = PLBertTrainer(cfg, 188, max_batch=2, max_seq=64, lr=1e-3, seed=1, force_collectives=True, comm='rccl', overlap=True)
 b = tr.stage_batch(labels, masked, lens, idx)
 tr.step(b); torch.cuda.synchronize()
-assert tr.engine.comm_pieces()[0] == 8
+assert tr.engine.comm_pieces()[0] == 10
 L = _lib.lib()
 L.plb_debug_skip_piece.argtypes = [__import__('ctypes').c_int]
 L.plb_debug_skip_piece(3)
@@ -275,12 +275,15 @@ def test_handoff_timeout_on_one_rank_is_every_ranks(fake_lib):
         assert np.array_equal(res[0][key]["params"], res[1][key]["params"]), key
 
 
-@pytest.mark.parametrize("forgotten", [0, 2, 3, 6, 13])
+@pytest.mark.parametrize("forgotten", [0, 2, 3, 5, 11, 14])
 def test_the_audit_sees_a_forgotten_wait(fake_lib, forgotten):
     """The happens-before audit must FIND a missing hipStreamWaitEvent: the model forgets the n-th wait of a step (the HIP call
     is still made, so nothing races for real) — 0: the head piece behind the head's weight gradient, 2: the side stream
-    behind the layer loop, 3: the Q/K/V piece behind its weight-gradient GEMM, 6: the small pieces behind the side
-    stream's join, 13: AdamW behind the communication stream — and the step (13: the next one) must fail, naming it."""
+    behind the layer loop, 3: the Q/K/V piece behind its weight-gradient GEMM, 5: the first of the five small pieces behind the
+    side stream's own event (the other four wait for the same point of that stream: implied by the first), 11: the last piece (dense.weight) behind its GEMM, 14: AdamW behind the communication stream — and
+    the step (14: the next one) must fail, naming it. (12, the main stream's join of the side stream at the end of the tail, is
+    implied in the overlapped form — AdamW waits for the communication stream, which has waited for the side stream's last
+    event — and is what orders the two in the serial form.)"""
     code = f"""
 import os, sys
 sys.path.insert(0, {ROOT!r})
