@@ -149,13 +149,13 @@ def cpu_baseline(budget_s):
 def _in_class(cls, name):
     import re
     if cls == "gemm_nt_small":
-        return re.search(r"gemm_nt_kernel<\d+, false>", name) is not None
+        return re.search(r"gemm_nt_kernel<\d+, false(, \d+)?>", name) is not None
     if cls == "gemm_nt_pipeline":  # every bf16 launch of the pipeline kernel with a bf16 output, whatever its epilogue
         m = re.search(r"gemm_nt_big_kernel<\d+, (\d+), (false|true), (?:false|true)(?:, (false|true))?(?:, (?:false|true))*>", name)
         return m is not None and m.group(2) == "false" and m.group(3) in (None, "false") and int(m.group(1)) in (0, 1, 2, 5, 6)
     if cls in ("gemm_nt", "gemm_nt_gelu", "gemm_nt_gelubwd", "gemm_nt_f32"):
         m = re.search(r"gemm_nt_big_kernel<\d+, (\d+), (false|true), (?:false|true)(?:, (?:false|true))*>", name) or \
-            (re.search(r"gemm_nt_kernel<(\d+), (true)>", name) if cls == "gemm_nt_f32" else None)
+            (re.search(r"gemm_nt_kernel<(\d+), (true)(?:, \d+)?>", name) if cls == "gemm_nt_f32" else None)
         if not m:
             return False
         act, f32 = int(m.group(1)), m.group(2) == "true"

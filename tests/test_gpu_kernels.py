@@ -22,7 +22,10 @@ def randbf(*shape, scale=1.0, seed=0):
     return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(DEV)
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (384, 768, 2048), (128, 188, 768)])
+# (the 128x128 kernel; grids of at most 256 workgroups with K >= 384 take its four-stage "deep" K loop: K-tile counts of 6, 7,
+#  12, 32 and 64 — every tail length of the counted waits)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (384, 768, 2048), (128, 188, 768), (128, 128, 384),
+                                   (256, 128, 448), (2048, 768, 2048), (1024, 1024, 4096), (128, 256, 320)])
 def test_gemm_nt_bias_residual(M, N, K):
     A, Bw = randbf(M, K, seed=1), randbf((N + 127) // 128 * 128, K, scale=0.05, seed=2)
     bias = torch.randn(N, device=DEV)
