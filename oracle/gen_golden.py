@@ -299,7 +299,7 @@ def capture_dualloss(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, n_s
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "dualloss" / "large" / "fullsize_a" / "fullsize_d": only those
+    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "dualloss" / "large" / "fullsize_a" / "fullsize_d" / "fullsize_ragged": only those
     real = dict(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
                 max_position_embeddings=512, num_hidden_layers=12)
     # (4) BASELINE configs[3]'s architecture (hidden 1024, 24 shared layers, 16 heads, FFN 4096; SURVEY.md section 8:
@@ -317,6 +317,14 @@ def main():
         return
     if only == "fullsize_d":
         capture_model("real_h1024_s512_b16", large, 188, 0, plbert_amd.synthetic_batch(16, 512, seed=1234), seed=0,
+                      full=False, n_steps=2, init="reference")
+        return
+    if only == "fullsize_ragged":
+        # the same size with RAGGED samples (N2, dataloader.py:276-297): 32 lengths between 64 and 512, longest first as the
+        # collater sorts them — attention tile skipping, padded rows and the pruned last application at 16,384 rows
+        rs = np.random.RandomState(77)
+        lengths = sorted([512] + rs.randint(64, 513, size=31).tolist(), reverse=True)
+        capture_model("real_s512_b32_ragged", real, 188, 0, ragged_batch(32, 512, lengths, seed=31), seed=0,
                       full=False, n_steps=2, init="reference")
         return
     if only in ("", "large"):

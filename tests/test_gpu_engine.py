@@ -115,7 +115,7 @@ def test_adamw_trajectory_small():
 
 
 @pytest.mark.parametrize("name,steps", [("real_s128_b8", 5), ("real_s512_b2_ragged", 2), ("real_h1024_s256_b4", 2),
-                                        ("real_s512_b32", 5), ("real_h1024_s512_b16", 2)])
+                                        ("real_s512_b32", 5), ("real_h1024_s512_b16", 2), ("real_s512_b32_ragged", 2)])
 def test_real_model_against_reference_probes(name, steps):
     """configs/config.yml model (768/12): loss, probe logits, grad norms, loss trajectory. real_h1024_s256_b4 is BASELINE
     configs[3]'s architecture (1024 / 24 layers / 16 heads / FFN 4096) captured from the reference at 4 x 256 = 1024
@@ -125,7 +125,9 @@ def test_real_model_against_reference_probes(name, steps):
     16 x 512 = 8,192 tokens: 128 / 64 row blocks, the weight-gradient split rule at 196,608 stacked rows, 384 / 256
     attention items), captured from the reference on exactly bench.py's rank-0 inputs — reference initialisation seed 0,
     synthetic_batch(B, 512, seed=1234), AdamW lr 7e-5; bench.py's own first steps are compared with the same fixtures
-    (its loss_parity entry)."""
+    (its loss_parity entry). real_s512_b32_ragged: the same size with 32 RAGGED samples (lengths 64 .. 512, longest first as
+    the collater sorts them, dataloader.py:276-297): attention tile skipping, padded rows and the pruned last application at
+    16,384 rows against the reference."""
     g = load_golden(name)
     eng, ocfg, pcfg, sd = _engine(g)
     masked, labels, lens, off, flat, n = _step_inputs(g)
