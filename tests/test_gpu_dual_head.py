@@ -69,6 +69,43 @@ def test_dual_adamw_trajectory_golden():
     assert torch.equal(eng.view("token_predictor.weight"), before)
 
 
+def test_dual_full_size_against_reference_probes():
+    """BASELINE configs[1] names a dual-head loss at 32 x 512: the reference's MultiTaskModel (768 / 12, a 5,000-token head
+    — not a multiple of the 256-column tile of the fused GEMM + cross-entropy passes) on bench.py's own batch and
+    initialisation, gradients by torch autograd over the reference model, AdamW lr 7e-5 (tests/golden/
+    real_s512_b32_dualloss.npz, oracle/gen_golden.py fullsize_dual; probes only). Both heads' logits on 16 probe rows, the
+    loss and its two parts, every gradient tensor's norm and 8 of its elements, the 2-step trajectory."""
+    g = load_golden("real_s512_b32_dualloss")
+    ocfg, pcfg, sd = golden_cfg(g)
+    B, S = g["labels"].shape
+    eng = HipEngine(pcfg, 188, int(g["num_tokens"]), max_batch=B, max_seq=S)
+    eng.load_state_dict(sd)
+    masked, labels, lens, off, flat, n, tok = _inputs(g)
+    _, ph, tk = eng.forward(masked, lens, want_token=True)
+    pb, ps = torch.as_tensor(g["probe_b"]), torch.as_tensor(g["probe_s"])
+    assert np.abs(ph[pb, ps].cpu().numpy() - g["probe_logits"]).max() < 3e-2
+    assert np.abs(tk[pb, ps].cpu().numpy() - g["probe_token_logits"]).max() < 3e-2
+    del tk
+    losses = []
+    for step in range(1, len(g["losses"]) + 1):
+        loss = eng.loss_fwd_bwd(masked, labels, lens, off, flat, n, token_ids=tok)
+        if step == 1:
+            torch.cuda.synchronize()
+            assert np.allclose(eng.loss_parts.cpu().numpy(), g["loss_parts"][0], rtol=1e-3)
+            for k, ref in zip(g["grad_names"], g["grad_l2"]):
+                k = str(k)
+                if k == KEY_BIAS:
+                    continue
+                got = eng.view(k, of=eng.grads)
+                assert abs(float(got.double().norm()) - ref) <= 3e-2 * ref + 1e-6, (k, float(got.double().norm()), ref)
+                flatg = got.flatten().cpu().numpy()
+                assert np.abs(flatg[g["gprobe_idx/" + k]] - g["gprobe_val/" + k]).max() <= 0.1 * np.abs(flatg).max() + 1e-7, k
+        losses.append(float(loss.item()))
+        eng.adamw_step(step, lr=float(g["lr"]))
+    assert np.allclose(losses, g["losses"], rtol=1e-3), (losses, g["losses"])
+    assert eng.status()["ln_exchange_timeouts"] == 0
+
+
 @pytest.mark.parametrize("num_tokens,B,S,lengths", [(1000, 3, 64, [64, 40, 9]), (2304, 2, 128, [128, 128])])
 def test_dual_against_oracle(num_tokens, B, S, lengths):
     """Seeded shapes vs the fp32 oracle: vocabulary not a multiple of 256 (padded columns), ragged lengths,
