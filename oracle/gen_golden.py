@@ -323,7 +323,7 @@ def capture_dualloss(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, n_s
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "dualloss" / "large" / "fullsize_a" / "fullsize_d" / "fullsize_ragged" / "fullsize_dual": only those
+    only = sys.argv[1] if len(sys.argv) > 1 else ""   # "dualloss" / "large" / "fullsize_a" / "fullsize_d" / "fullsize_ragged" / "fullsize_dual" / "fullsize_b96": only those
     real = dict(vocab_size=188, hidden_size=768, num_attention_heads=12, intermediate_size=2048,
                 max_position_embeddings=512, num_hidden_layers=12)
     # (4) BASELINE configs[3]'s architecture (hidden 1024, 24 shared layers, 16 heads, FFN 4096; SURVEY.md section 8:
@@ -349,6 +349,12 @@ def main():
         rs = np.random.RandomState(77)
         lengths = sorted([512] + rs.randint(64, 513, size=31).tolist(), reverse=True)
         capture_model("real_s512_b32_ragged", real, 188, 0, ragged_batch(32, 512, lengths, seed=31), seed=0,
+                      full=False, n_steps=2, init="reference")
+        return
+    if only == "fullsize_b96":
+        # configs/config.yml's own batch_size (96 x 512 = 49,152 rows: 384 row blocks, 1,152 attention items, 589,824 stacked
+        # rows in the weight-gradient GEMMs), reference initialisation, 2 AdamW steps; probes only (~90 s of CPU per step)
+        capture_model("real_s512_b96", real, 188, 0, plbert_amd.synthetic_batch(96, 512, seed=1234), seed=0,
                       full=False, n_steps=2, init="reference")
         return
     if only == "fullsize_dual":

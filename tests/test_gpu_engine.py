@@ -115,7 +115,8 @@ def test_adamw_trajectory_small():
 
 
 @pytest.mark.parametrize("name,steps", [("real_s128_b8", 5), ("real_s512_b2_ragged", 2), ("real_h1024_s256_b4", 2),
-                                        ("real_s512_b32", 5), ("real_h1024_s512_b16", 2), ("real_s512_b32_ragged", 2)])
+                                        ("real_s512_b32", 5), ("real_h1024_s512_b16", 2), ("real_s512_b32_ragged", 2),
+                                        ("real_s512_b96", 2)])
 def test_real_model_against_reference_probes(name, steps):
     """configs/config.yml model (768/12): loss, probe logits, grad norms, loss trajectory. real_h1024_s256_b4 is BASELINE
     configs[3]'s architecture (1024 / 24 layers / 16 heads / FFN 4096) captured from the reference at 4 x 256 = 1024
@@ -127,7 +128,8 @@ def test_real_model_against_reference_probes(name, steps):
     synthetic_batch(B, 512, seed=1234), AdamW lr 7e-5; bench.py's own first steps are compared with the same fixtures
     (its loss_parity entry). real_s512_b32_ragged: the same size with 32 RAGGED samples (lengths 64 .. 512, longest first as
     the collater sorts them, dataloader.py:276-297): attention tile skipping, padded rows and the pruned last application at
-    16,384 rows against the reference."""
+    16,384 rows against the reference. real_s512_b96: configs/config.yml's own batch_size (49,152 rows: 384 row blocks, 1,152
+    attention items, 589,824 stacked rows in the weight-gradient GEMMs)."""
     g = load_golden(name)
     eng, ocfg, pcfg, sd = _engine(g)
     masked, labels, lens, off, flat, n = _step_inputs(g)

@@ -1,7 +1,7 @@
 """configs/config.yml's own batch on ONE GPU (-m gpu): batch_size 96 x seq 512 = 49,152 tokens
 (/root/reference/configs/config.yml:16, modal_main.py:43 trains it on one A100). Round 1 refused any batch above
-38,400 tokens in the embedding-gradient scatter. No golden exists at this size (the reference needs minutes per
-step on CPU), so the step is checked through size-independent properties: the embedding gradients against a torch
+38,400 tokens in the embedding-gradient scatter. The reference comparison at this size is tests/golden/real_s512_b96.npz
+(round 5, test_gpu_engine.py::test_real_model_against_reference_probes); here the step is checked through size-independent properties: the embedding gradients against a torch
 index_add over the kernel's own per-token gradient rows, gradient sums that must vanish, and agreement of the
 batch's loss with the mean of its three 32-sample thirds (every sample has masked phonemes, so the per-sample-mean
 loss is linear in the samples)."""
