@@ -416,11 +416,11 @@ def pipeline_lines():
 def loss_parity(trainer, batch, args, world, B, S):
     """The metric's LOSS half at the size it is quoted on: the first steps of this very run — fresh reference-initialised
     weights (seed 0), rank 0's batch synthetic_batch(B, 512, seed=1234), AdamW lr 7e-5 — against the loss trajectory the
-    REFERENCE produced on the same inputs in the build container (tests/golden/real_s512_b32.npz / real_h1024_s512_b16.npz,
+    REFERENCE produced on the same inputs in the build container (tests/golden/real_s512_b32.npz / real_s512_b96.npz (--batch 96) / real_h1024_s512_b16.npz,
     captured by oracle/gen_golden.py fullsize_a / fullsize_d from /root/reference's process_batch + torch AdamW; data
     fixtures, nothing of the reference runs here). N > 1: the ranks' batches differ, so only the first loss (before any
     update) is comparable. Called before anything else has stepped the trainer; returns the JSON entry (rank 0) or None."""
-    name = {"base": "real_s512_b32", "large": "real_h1024_s512_b16"}[args.model]
+    name = {"base": "real_s512_b96" if B == 96 else "real_s512_b32", "large": "real_h1024_s512_b16"}[args.model]
     path = os.path.join(ROOT, "tests", "golden", name + ".npz")
     if args.num_tokens or S != 512 or not os.path.exists(path):
         return None
