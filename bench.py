@@ -220,7 +220,8 @@ def secondary_lines():
     import subprocess
 
     out = {}
-    for key, extra in (("large", ["--model", "large"]), ("fp8", ["--dtype", "fp8"]), ("large_fp8", ["--model", "large", "--dtype", "fp8"])):
+    for key, extra in (("large", ["--model", "large"]), ("fp8", ["--dtype", "fp8"]), ("large_fp8", ["--model", "large", "--dtype", "fp8"]),
+                       ("dual_head", ["--num-tokens", "5000", "--no-roofline"])):   # configs[1]'s "dual-head loss", anchored to the reference
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", "40", "--warmup", "8", "--no-cpu-baseline",
                "--no-traffic", "--no-staged", "--no-secondary", *extra]
         note(f"secondary.{key}")
@@ -421,18 +422,22 @@ def loss_parity(trainer, batch, args, world, B, S):
     fixtures, nothing of the reference runs here). N > 1: the ranks' batches differ, so only the first loss (before any
     update) is comparable. Called before anything else has stepped the trainer; returns the JSON entry (rank 0) or None."""
     name = {"base": "real_s512_b96" if B == 96 else "real_s512_b32", "large": "real_h1024_s512_b16"}[args.model]
-    path = os.path.join(ROOT, "tests", "golden", name + ".npz")
-    if args.num_tokens or S != 512 or not os.path.exists(path):
+    if args.num_tokens:   # dual-head step: the reference's MultiTaskModel with a 5,000-token head under the upstream token loss
+        name = "real_s512_b32_dualloss" if (args.model == "base" and args.num_tokens == 5000) else None
+    path = os.path.join(ROOT, "tests", "golden", str(name) + ".npz")
+    if name is None or S != 512 or not os.path.exists(path):
         return None
     g = np.load(path, allow_pickle=True)
-    if g["labels"].shape != (B, S):
+    if g["labels"].shape != (B, S) or (args.num_tokens and int(g["num_tokens"]) != args.num_tokens):
         return None
     ref = [float(x) for x in g["losses"]]
     n = len(ref) if world == 1 else 1
     got = [float(trainer.step(batch).item()) for _ in range(n)]
     rel = [abs(a - b) / abs(b) for a, b in zip(got, ref)]
     tol = 1e-3 if args.dtype == "bf16" else 2e-2
-    return {"fixture": f"tests/golden/{name}.npz (reference process_batch + AdamW on bench.py's rank-0 inputs)",
+    how = ("reference MultiTaskModel, phoneme loss + upstream token loss, torch autograd + AdamW" if args.num_tokens
+           else "reference process_batch + AdamW")
+    return {"fixture": f"tests/golden/{name}.npz ({how} on bench.py's rank-0 inputs)",
             "ref": [round(x, 6) for x in ref[:n]], "got": [round(x, 6) for x in got], "max_rel": float(f"{max(rel):.3e}"),
             "tol": tol, "ok": bool(max(rel) <= tol), "steps_compared": n,
             "note": None if args.dtype == "bf16" else "fp8 call: step 1 is the bf16 calibration call; tolerance is the mode's own 2e-2"}

@@ -246,7 +246,8 @@ def capture_model(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, full, 
     print(tag, "written; loss", out.get("loss"), "sdpa delta", out["sdpa_max_abs_delta_valid_rows"])
 
 
-def capture_dualloss(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, n_steps, lr=1e-3, full=True, init="deterministic"):
+def capture_dualloss(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, n_steps, lr=1e-3, full=True, init="deterministic",
+                     token_ids=None):
     """Dual-head training on the reference's MultiTaskModel: loss = calculate_phoneme_loss (train.py:107-131)
     + the token loss of oracle.albert_np.token_loss (per-sample mean CE over [:length], mean over samples —
     upstream PL-BERT's loss_vocab; the reference itself has no token loss). torch autograd + AdamW."""
@@ -254,10 +255,11 @@ def capture_dualloss(tag, cfg_kwargs, num_phonemes, num_tokens, batch, seed, n_s
     gen = plbert_amd.deterministic_state_dict if init == "deterministic" else plbert_amd.reference_init_state_dict
     sd = gen(pcfg, num_phonemes, num_tokens, seed=seed)
     labels, masked, lengths, idxs = batch
-    rs = np.random.RandomState(seed + 1000)
-    token_ids = np.zeros_like(labels)
-    for b, L in enumerate(lengths):
-        token_ids[b, :L] = rs.randint(0, num_tokens, size=L)
+    if token_ids is None:
+        rs = np.random.RandomState(seed + 1000)
+        token_ids = np.zeros_like(labels)
+        for b, L in enumerate(lengths):
+            token_ids[b, :L] = rs.randint(0, num_tokens, size=L)
     out = dict(labels=labels, masked=masked, lengths=np.array(lengths), index=obj_array(idxs), token_ids=token_ids,
                seed=np.array(seed), num_phonemes=np.array(num_phonemes), num_tokens=np.array(num_tokens),
                cfg_keys=np.array(list(cfg_kwargs.keys())), cfg_vals=np.array(list(cfg_kwargs.values())))
@@ -361,8 +363,10 @@ def main():
         # BASELINE configs[1]'s "dual-head loss" at its stated size: MultiTaskModel 768/12 with a 5,000-token head (not a
         # multiple of the 256-column tile of the fused GEMM + cross-entropy passes), bench.py's batch and initialisation,
         # torch autograd over the reference model for the gradients, AdamW lr 7e-5, 2 steps; probes only
+        # (token targets as bench.py --num-tokens draws them on rank 0, so that its first steps are comparable)
         capture_dualloss("real_s512_b32_dualloss", real, 188, 5000, plbert_amd.synthetic_batch(32, 512, seed=1234), seed=0,
-                         n_steps=2, lr=7e-5, full=False, init="reference")
+                         n_steps=2, lr=7e-5, full=False, init="reference",
+                         token_ids=np.random.RandomState(4321).randint(0, 5000, size=(32, 512)).astype(np.int64))
         return
     if only in ("", "large"):
         capture_model("real_h1024_s256_b4", large, 188, 0, ragged_batch(4, 256, [256, 256, 256, 201], seed=8), seed=24,
