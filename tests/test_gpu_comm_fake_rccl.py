@@ -314,15 +314,16 @@ else:
     assert "CAUGHT" in r.stdout, r.stdout[-2000:]
 
 
-def test_bench_at_world_2_through_the_engines_own_exchange(fake_lib):
-    """`python bench.py --gpus 2 --comm rccl` with the stand-in library: the rehearsal of the driver's N > 1 run that one GPU
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_bench_at_world_2_through_the_engines_own_exchange(fake_lib, ranks):
+    """`python bench.py --gpus N --comm rccl` (N = 2, 4: ranks sharing the one GPU) with the stand-in library: the rehearsal of the driver's N > 1 run that one GPU
     allows — bench.py's own launcher, two real processes, the unique id travelling over the control plane, plb_comm_init at
     world 2, the overlapped-vs-serial calibration agreed between the ranks, the piece trace, the exposed-exchange figures and
     ONE JSON line from rank 0 (the 8-GPU scaling run issues exactly this sequence with librccl in the stand-in's place)."""
     import json
     env = dict(os.environ, PYTHONPATH=ROOT, PLBERT_RCCL_LIB=fake_lib, FAKE_RCCL_TIMEOUT_S="120")
     env.pop("MASTER_PORT", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm", "rccl", "--steps", "4",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--comm", "rccl", "--steps", "4",
                         "--warmup", "2", "--batch", "4", "--seq", "128", "--no-cpu-baseline", "--no-traffic", "--no-roofline"],
                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-4000:]
@@ -330,8 +331,8 @@ def test_bench_at_world_2_through_the_engines_own_exchange(fake_lib):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     c = out["comm"]
-    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["config"]["global_batch"] == 8
-    assert c["mode"] == "rccl" and c["world"] == 2, c
+    assert out["n_gpus"] == ranks and out["ranks_seen"] == ranks and out["config"]["global_batch"] == 4 * ranks
+    assert c["mode"] == "rccl" and c["world"] == ranks, c
     assert c["pieces_per_step"] in (1, 10), c                         # the form the calibration kept: serial or overlapped
     tr = c["piece_trace"]
     assert len(tr["pieces"]) == 10 and all(p["done_ms"] >= p["released_ms"] for p in tr["pieces"]), tr
