@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import os
+
 import numpy as np
 import torch
 
@@ -108,8 +110,8 @@ class PLBertTrainer:
         self.engine._on_handoff_timeout.append(_rewind_steps(self))
         self.comm = "none"
         if self.reducer.active:
-            if comm == "auto":
-                comm = "rccl" if own_gpu_per_rank() else "torch"
+            if comm == "auto":   # PLBERT_COMM=rccl|torch overrides (tests: the engine's own exchange through a stand-in library)
+                comm = os.environ.get("PLBERT_COMM") or ("rccl" if own_gpu_per_rank() else "torch")
             if comm == "rccl":
                 uid = exchange_unique_id(HipEngine.comm_unique_id if self.reducer.rank == 0 else None, process_group)
                 self.engine.comm_init(uid, self.reducer.rank, self.world)

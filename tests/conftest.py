@@ -39,3 +39,17 @@ def golden_cfg(g):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def fake_lib(tmp_path_factory):
+    """tests/fake_rccl.cpp built once per session: RCCL's entry points over POSIX shared memory between processes that share
+    the GPU (PLBERT_RCCL_LIB) — the engine's own gradient exchange at world > 1 on a one-GPU box."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out,
+                        os.path.join(root, "tests", "fake_rccl.cpp"), "-lrt", "-lpthread"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    return out

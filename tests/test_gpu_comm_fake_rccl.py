@@ -21,16 +21,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def fake_lib(tmp_path_factory):
-    out = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
-    r = subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", out,
-                        os.path.join(ROOT, "tests", "fake_rccl.cpp"), "-lrt", "-lpthread"],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-    assert r.returncode == 0, r.stdout
-    return out
-
-
 def _setup(num_tokens, real=False):
     """real: the model and per-rank shape class of the bench (768 / 12 layers / 12 heads / FFN 2048, 2 x 512 = 1024 tokens
     per rank): the launches between the pieces are then the fused LayerNorm + gelu-stash forms and the 256x256 token-major

@@ -104,10 +104,10 @@ def test_deferred_loss_readback_logs_what_the_immediate_one_logs(tmp_path, monke
     assert [r["step"] for r in out[True][0] if "phoneme_loss" in r] == list(range(1, 8))
 
 
-def _launched_rank(rank, world, port, args, docs, out):
+def _launched_rank(rank, world, port, args, docs, out, env=None):
     # what torchrun / accelerate launch export: train() must join the group and pick its GPU from these alone
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), **(env or {}))
     import torch.distributed as dist
     from plbert_amd import data as pdata_, run as prun_
 
@@ -119,14 +119,16 @@ def _launched_rank(rank, world, port, args, docs, out):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sharded", [False, True])
-def test_train_under_a_launcher_two_ranks(tmp_path, sharded):
+@pytest.mark.parametrize("sharded,exchange", [(False, "torch"), (True, "torch"), (False, "rccl")])
+def test_train_under_a_launcher_two_ranks(tmp_path, fake_lib, sharded, exchange):
     """``train(args)`` started as two ranks (RANK / WORLD_SIZE / LOCAL_RANK in the environment, nothing else): each rank
     joins the process group itself and takes GPU LOCAL_RANK (both map to the box's one GPU here), rank 0 alone creates
     the run directory, writes metrics and checkpoints, the ragged last validation batch (7 documents, batch 4, two
     ranks) is shared out instead of raising, and the replicas end bit-identical. Every rank's batches come through the
     DeviceFeeder (copy stream, double-buffered slots). ``sharded``: training_params.shard_samples — each rank loads and masks
-    only its own half of the samples (batches of 2), with the masking applied on the device."""
+    only its own half of the samples (batches of 2), with the masking applied on the device. ``exchange == "rccl"``: the
+    ranks exchange through the ENGINE's communicator (what a run with one GPU per rank uses: pieces inside the backward,
+    health word, deferred loss read-back) over the stand-in library of tests/fake_rccl.cpp, PLBERT_COMM=rccl."""
     import torch.multiprocessing as mp
 
     path = _config(tmp_path, 4, **(dict(shard_samples=True, device_masking=True, num_workers=2) if sharded else {}))
@@ -136,10 +138,11 @@ def test_train_under_a_launcher_two_ranks(tmp_path, sharded):
     port = 29700 + (os.getpid() % 2000)
     with mp.Manager() as mgr:
         out = mgr.dict()
-        mp.spawn(_launched_rank, args=(2, port, args, docs, out), nprocs=2, join=True)
+        env = dict(PLBERT_COMM="rccl", PLBERT_RCCL_LIB=fake_lib, FAKE_RCCL_TIMEOUT_S="120") if exchange == "rccl" else None
+        mp.spawn(_launched_rank, args=(2, port, args, docs, out, env), nprocs=2, join=True)
         res = dict(out)
     assert res[0][0] == res[1][0] == 4 and res[0][1] == res[1][1] == 2
-    assert res[0][2] == res[1][2] == "torch"              # two ranks on one device: the gloo fallback, not RCCL
+    assert res[0][2] == res[1][2] == exchange             # two ranks on one device: the gloo fallback unless told otherwise
     assert np.array_equal(res[0][4], res[1][4])
     run_dir = tmp_path / "runs" / "two"
     assert sorted(f for f in os.listdir(run_dir) if f.startswith("step_")) == ["step_3.pth"]
